@@ -1,0 +1,111 @@
+"""Shared helpers for the parity tests (CPU side: builds oracle parameter dicts)."""
+import os
+import zlib
+
+import numpy as np
+import torch
+
+from transvae_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+CONFIGS = {
+    "1x128_zinc": dict(arch="trans1x-128", vocab="zinc", pp=False),
+    "4x256_zinc": dict(arch="trans4x-256", vocab="zinc", pp=False),
+    "4x256_pubchem_pp": dict(arch="trans4x-256", vocab="pubchem", pp=True),
+}
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+def state_shapes(d_model, d_ff, pp=False, N=3, d_latent=128, vocab=26, d_pp=256, depth_pp=2):
+    """Key -> shape table of the reference's state_dict, built from first
+    principles so the oracle does not need the product's modules."""
+    S = {}
+
+    def lin(k, o, i):
+        S[k + ".weight"] = (o, i)
+        S[k + ".bias"] = (o,)
+
+    def attn(k):
+        for j in range(4):
+            lin("%s.linears.%d" % (k, j), d_model, d_model)
+
+    def enc_layer(k):
+        attn(k + ".self_attn")
+        lin(k + ".feed_forward.w_1", d_ff, d_model)
+        lin(k + ".feed_forward.w_2", d_model, d_ff)
+        for j in range(2):
+            S["%s.sublayer.%d.norm.a_2" % (k, j)] = (d_model,)
+            S["%s.sublayer.%d.norm.b_2" % (k, j)] = (d_model,)
+
+    for i in range(N):
+        enc_layer("encoder.layers.%d" % i)
+    c = d_model
+    for i, ksz in enumerate((9, 8, 8)):
+        o = 64 if i == 2 else (c - 64) // 2 + 64
+        S["encoder.conv_bottleneck.conv_layers.%d.0.weight" % i] = (o, c, ksz)
+        S["encoder.conv_bottleneck.conv_layers.%d.0.bias" % i] = (o,)
+        c = o
+    lin("encoder.z_means", d_latent, 576)
+    lin("encoder.z_var", d_latent, 576)
+    S["encoder.norm.a_2"] = (d_model,)
+    S["encoder.norm.b_2"] = (d_model,)
+    lin("encoder.predict_len1", 2 * d_latent, d_latent)
+    lin("encoder.predict_len2", d_latent, 2 * d_latent)
+    enc_layer("decoder.final_encodes.0")
+    for i in range(N):
+        k = "decoder.layers.%d" % i
+        attn(k + ".self_attn")
+        attn(k + ".src_attn")
+        lin(k + ".feed_forward.w_1", d_ff, d_model)
+        lin(k + ".feed_forward.w_2", d_model, d_ff)
+        for j in range(3):
+            S["%s.sublayer.%d.norm.a_2" % (k, j)] = (d_model,)
+            S["%s.sublayer.%d.norm.b_2" % (k, j)] = (d_model,)
+    S["decoder.norm.a_2"] = (d_model,)
+    S["decoder.norm.b_2"] = (d_model,)
+    lin("decoder.linear", 576, d_latent)
+    c = 64
+    for i in range(3):
+        o = d_model if i == 2 else (d_model - c) // 4 + c
+        S["decoder.deconv_bottleneck.deconv_layers.%d.0.weight" % i] = (c, o, 11)
+        S["decoder.deconv_bottleneck.deconv_layers.%d.0.bias" % i] = (o,)
+        c = o
+    S["src_embed.0.lut.weight"] = (vocab, d_model)
+    S["tgt_embed.0.lut.weight"] = (vocab, d_model)
+    lin("generator.proj", vocab - 1, d_model)
+    if pp:
+        for i in range(depth_pp):
+            lin("property_predictor.prediction_layers.%d" % i,
+                1 if i == depth_pp - 1 else d_pp, d_latent if i == 0 else d_pp)
+    return S
+
+
+def oracle_params(cfg_name, dtype=torch.float32, seed=0, requires_grad=False):
+    """Synthetic checkpoint as an oracle parameter dict (same bits as the golden run)."""
+    from oracle import tvae_oracle as O
+    cfg = CONFIGS[cfg_name]
+    arch = synth.ARCHS[cfg["arch"]]
+    shapes = state_shapes(arch["d_model"], arch["d_ff"], cfg["pp"])
+    P = {k: torch.from_numpy(synth.synth_tensor(k, s, seed)).to(dtype) for k, s in shapes.items()}
+    if requires_grad:
+        for v in P.values():
+            v.requires_grad_(True)
+    pe = O.positional_table(5000, arch["d_model"]).unsqueeze(0)
+    P["src_embed.1.pe"] = pe.to(dtype)
+    P["tgt_embed.1.pe"] = pe.to(dtype)
+    return P
+
+
+def probe_vec(key, n):
+    rng = np.random.default_rng(zlib.crc32(("probe:" + key).encode()))
+    return rng.standard_normal(n)
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, dtype=np.float64).ravel()
+    b = np.asarray(b, dtype=np.float64).ravel()
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))

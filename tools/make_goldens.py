@@ -1,0 +1,347 @@
+#!/usr/bin/env python3
+"""Capture golden vectors from the REAL reference (container only; never runs on the GPU box).
+
+Imports /root/reference/transvae with rdkit/seaborn stubbed (both absent here and untouched
+by the hot path), loads the synthetic checkpoints of transvae_amd.synth into
+the reference's own nn.Modules, runs its forward / loss / backward / NoamOpt step /
+greedy_decode / forward_w_attn and writes small .npz fixtures into tests/golden/.
+
+    python tools/make_goldens.py            # regenerates tests/golden/*.npz
+
+The fixtures are data (inputs + expected outputs).  No reference source is copied.
+"""
+import os
+import sys
+import types
+import zlib
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def import_reference():
+    for name in ["rdkit", "rdkit.Chem", "rdkit.Chem.AllChem", "rdkit.Chem.Descriptors",
+                 "rdkit.rdBase", "seaborn"]:
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["rdkit.rdBase"].DisableLog = lambda *_: None
+    sys.modules["rdkit.Chem.AllChem"].GetMorganFingerprintAsBitVect = None
+    sys.modules["rdkit"].rdBase = sys.modules["rdkit.rdBase"]
+    sys.modules["rdkit"].Chem = sys.modules["rdkit.Chem"]
+    sys.modules["rdkit.Chem"].Descriptors = sys.modules["rdkit.Chem.Descriptors"]
+    sys.modules["rdkit.Chem"].AllChem = sys.modules["rdkit.Chem.AllChem"]
+    sys.path.insert(0, REF)
+    import transvae.trans_models as tm
+    import transvae.loss as loss
+    import transvae.data as data
+    import transvae.tvae_util as util
+    import transvae.opt as opt
+    return tm, loss, data, util, opt
+
+
+def probe_vec(key, n):
+    """Seeded N(0,1) probe: the golden stores <grad, probe> per tensor."""
+    rng = np.random.default_rng(zlib.crc32(("probe:" + key).encode()))
+    return rng.standard_normal(n)
+
+
+FULL_GRAD_KEYS = [
+    "encoder.layers.0.sublayer.0.norm.a_2", "encoder.layers.0.sublayer.0.norm.b_2",
+    "decoder.layers.2.sublayer.2.norm.a_2", "decoder.layers.2.sublayer.2.norm.b_2",
+    "decoder.norm.a_2", "encoder.norm.b_2", "generator.proj.weight", "generator.proj.bias",
+    "encoder.z_means.bias", "encoder.z_var.bias",
+    "encoder.conv_bottleneck.conv_layers.0.0.bias", "encoder.conv_bottleneck.conv_layers.2.0.bias",
+    "decoder.deconv_bottleneck.deconv_layers.2.0.bias", "decoder.deconv_bottleneck.deconv_layers.0.0.bias",
+    "src_embed.0.lut.weight", "tgt_embed.0.lut.weight",
+    "encoder.layers.1.self_attn.linears.0.bias", "decoder.layers.1.src_attn.linears.2.bias",
+    "encoder.predict_len2.bias", "decoder.linear.bias",
+]
+
+CONFIGS = {
+    "1x128_zinc": dict(arch="trans1x-128", vocab="zinc", pp=False),
+    "4x256_zinc": dict(arch="trans4x-256", vocab="zinc", pp=False),
+    "4x256_pubchem_pp": dict(arch="trans4x-256", vocab="pubchem", pp=True),
+}
+
+
+def build(tm, cfg, seed=0, **extra):
+    from transvae_amd import synth
+    char_dict, org_dict, w = synth.load_vocab(cfg["vocab"])
+    params = {"CHAR_DICT": char_dict, "ORG_DICT": org_dict, "CHAR_WEIGHTS": w}
+    params.update(extra)
+    vae = tm.TransVAE(params=params, name="golden", property_predictor=cfg["pp"],
+                      **synth.ARCHS[cfg["arch"]])
+    sd = synth.synth_state_dict(vae.model.state_dict(), seed)
+    vae.model.load_state_dict(sd)
+    return vae
+
+
+def step_inputs(cfg_name, B=12):
+    from transvae_amd import synth
+    lens = [1, 2, 126, 125, 35, 40, 22, 60, 90, 33, 47, 10][:B]
+    toks = synth.synth_tokens(B, seed=zlib.crc32(cfg_name.encode()) & 0xFFFF, lengths=lens)
+    rng = np.random.default_rng(7)
+    eps = torch.from_numpy(rng.standard_normal((B, 128)).astype(np.float32))
+    props = torch.from_numpy(rng.uniform(0, 3, B).astype(np.float32))
+    return toks, props, eps
+
+
+def run_chunk(tm, loss_mod, data_mod, vae, toks, props, eps, beta, dtype):
+    """One chunk exactly as VAEShell.train does it (trans_models.py:211-236), eval mode."""
+    model = vae.model
+    model.to(dtype)
+    model.eval()
+    model.zero_grad()
+    src = toks.long()
+    tgt = toks[:, :-1].long()
+    src_mask = (src != vae.pad_idx).unsqueeze(-2)
+    tgt_mask = data_mod.make_std_mask(tgt, vae.pad_idx)
+    orig = torch.randn_like
+    torch.randn_like = lambda t, *a, **k: eps.to(t.dtype)
+    try:
+        x_out, mu, logvar, pred_len, pred_prop = model(src, tgt, src_mask, tgt_mask)
+    finally:
+        torch.randn_like = orig
+    true_len = src_mask.sum(dim=-1)
+    w = vae.params["CHAR_WEIGHTS"].to(dtype)
+    out = loss_mod.trans_vae_loss(src, x_out, mu, logvar, true_len, pred_len,
+                                  props.to(dtype), pred_prop, w, beta)
+    out[0].backward()
+    return out, x_out, mu, logvar, pred_len, pred_prop
+
+
+def golden_step(tm, loss_mod, data_mod, name, cfg):
+    vae = build(tm, cfg)
+    toks, props, eps = step_inputs(name)
+    beta = 0.02
+    rec = dict(tokens=toks.numpy().astype(np.int8), props=props.numpy(), eps=eps.numpy(),
+               beta=np.float64(beta))
+    for tag, dtype in (("f32", torch.float32), ("f64", torch.float64)):
+        out, x_out, mu, logvar, pred_len, pred_prop = run_chunk(
+            tm, loss_mod, data_mod, vae, toks, props, eps, beta, dtype)
+        rec["loss_" + tag] = np.array([float(o) for o in out], dtype=np.float64)
+        if tag == "f32":
+            rec["mu"] = mu.detach().numpy()
+            rec["logvar"] = logvar.detach().numpy()
+            rec["pred_len"] = pred_len.detach().numpy()
+            rec["logits_rows"] = x_out.detach()[[0, 2, 5]].numpy()
+            if pred_prop is not None:
+                rec["pred_prop"] = pred_prop.detach().numpy()
+        keys, norms, sums, dots = [], [], [], []
+        for k, p in vae.model.named_parameters():
+            g = p.grad.detach().double().numpy().ravel()
+            keys.append(k)
+            norms.append(np.sqrt((g * g).sum()))
+            sums.append(g.sum())
+            dots.append(float(g @ probe_vec(k, g.size)))
+        rec["grad_keys"] = np.array(keys)
+        rec["grad_norm_" + tag] = np.array(norms)
+        rec["grad_sum_" + tag] = np.array(sums)
+        rec["grad_dot_" + tag] = np.array(dots)
+        if tag == "f64":
+            named = dict(vae.model.named_parameters())
+            for k in FULL_GRAD_KEYS:
+                rec["grad_full/" + k] = named[k].grad.detach().numpy().astype(np.float64)
+    vae.model.float()
+    np.savez_compressed(os.path.join(OUT, "step_%s.npz" % name), **rec)
+    print("step", name, rec["loss_f32"], rec["loss_f64"])
+
+
+def golden_accum(tm, loss_mod, data_mod):
+    """2 chunks accumulated, NoamOpt.step, 3 steps (trans1x-128)."""
+    from transvae_amd import synth
+    name, cfg = "1x128_zinc", CONFIGS["1x128_zinc"]
+    vae = build(tm, cfg, WARMUP_STEPS=100)   # short warm-up so that updates are well above fp32 eps
+    keys = ["generator.proj.bias", "encoder.norm.a_2", "encoder.z_means.bias",
+            "decoder.layers.0.self_attn.linears.3.bias", "src_embed.0.lut.weight",
+            "encoder.conv_bottleneck.conv_layers.1.0.bias", "decoder.linear.bias",
+            "decoder.layers.2.feed_forward.w_2.bias", "encoder.predict_len1.bias",
+            "decoder.deconv_bottleneck.deconv_layers.1.0.bias"]
+    rec = {"keys": np.array(keys)}
+    rng = np.random.default_rng(11)
+    all_toks, all_eps, rates, losses = [], [], [], []
+    named = dict(vae.model.named_parameters())
+    for step in range(3):
+        vae.model.zero_grad()
+        for c in range(2):
+            toks = synth.synth_tokens(6, seed=100 + 10 * step + c)
+            eps = torch.from_numpy(rng.standard_normal((6, 128)).astype(np.float32))
+            props = torch.zeros(6)
+            all_toks.append(toks.numpy().astype(np.int8))
+            all_eps.append(eps.numpy())
+            model = vae.model
+            model.eval()
+            src = toks.long()
+            tgt = toks[:, :-1].long()
+            src_mask = (src != vae.pad_idx).unsqueeze(-2)
+            tgt_mask = data_mod.make_std_mask(tgt, vae.pad_idx)
+            orig = torch.randn_like
+            torch.randn_like = lambda t, *a, **k: eps.to(t.dtype)
+            try:
+                x_out, mu, logvar, pred_len, pred_prop = model(src, tgt, src_mask, tgt_mask)
+            finally:
+                torch.randn_like = orig
+            out = loss_mod.trans_vae_loss(src, x_out, mu, logvar, src_mask.sum(dim=-1), pred_len,
+                                          props, pred_prop, vae.params["CHAR_WEIGHTS"], 0.01)
+            losses.append(float(out[0]))
+            out[0].backward()
+        vae.optimizer.step()
+        rates.append(vae.optimizer.state_dict["rate"])
+        for k in keys:
+            rec["p_step%d/%s" % (step + 1, k)] = named[k].detach().numpy().copy()
+    rec.update(tokens=np.stack(all_toks), eps=np.stack(all_eps), rates=np.array(rates),
+               losses=np.array(losses), beta=np.float64(0.01), warmup=np.int64(100))
+    np.savez_compressed(os.path.join(OUT, "accum_1x128_zinc.npz"), **rec)
+    print("accum rates", rates)
+
+
+def golden_decode(tm, name, cfg, n=32):
+    vae = build(tm, cfg)
+    vae.use_gpu = False
+    # shift the length head so predicted mask lengths are spread out (incl. a 0 case):
+    # the bias of predict_len2 is part of the synthetic checkpoint, so the build sees it too.
+    z = torch.from_numpy(np.random.default_rng(3).standard_normal((n, 128)).astype(np.float32))
+    with torch.no_grad():
+        mask_len = vae.model.encoder.predict_mask_length(z).squeeze(-1)
+        ids = vae.greedy_decode(z)
+        ids_cond = vae.greedy_decode(z[:8], condition=["C", "c"])
+        lens = torch.tensor([0, 1, 5, 17, 40, 77, 126, 127])
+        sm = (torch.arange(127)[None, :] < lens[:, None]).float().unsqueeze(1)
+        ids_mask = vae.greedy_decode(z[8:16], src_mask=sm)
+    # per-step top-2 logit margin, from a straight-line replay of the same loop
+    gaps = np.zeros((n, 125), dtype=np.float32)
+    with torch.no_grad():
+        src_mask = torch.zeros(n, 1, 127)
+        for i in range(n):
+            src_mask[i, :, :int(mask_len[i])] = 1
+        dec = torch.zeros(n, 1, dtype=torch.long)
+        vae.model.eval()
+        for i in range(125):
+            out = vae.model.generator(vae.model.decode(z, src_mask, dec, tm.subsequent_mask(dec.size(1)).long()))
+            t2 = torch.topk(out[:, i, :], 2, dim=-1)[0]
+            gaps[:, i] = (t2[:, 0] - t2[:, 1]).numpy()
+            nxt = torch.max(out[:, i, :], dim=1)[1] + 1
+            assert torch.equal(nxt, ids[:, i]), "replay diverged"
+            dec = torch.cat([dec, nxt.unsqueeze(1)], 1)
+    np.savez_compressed(os.path.join(OUT, "decode_%s.npz" % name), z=z.numpy(),
+                        mask_len=mask_len.numpy().astype(np.int16), ids=ids.numpy().astype(np.int8),
+                        ids_cond=ids_cond.numpy().astype(np.int8), cond=np.array(["C", "c"]),
+                        mask_lens_explicit=lens.numpy().astype(np.int16),
+                        ids_mask=ids_mask.numpy().astype(np.int8), margins=gaps)
+    print("decode", name, "mask_len", mask_len.tolist(), "min margin", gaps.min(),
+          "distinct tokens", len(np.unique(ids.numpy())))
+
+
+def golden_attn(tm, data_mod):
+    name, cfg = "1x128_zinc", CONFIGS["1x128_zinc"]
+    vae = build(tm, cfg)
+    from transvae_amd import synth
+    toks = synth.synth_tokens(2, seed=5, lengths=[30, 126])
+    eps = torch.from_numpy(np.random.default_rng(9).standard_normal((2, 128)).astype(np.float32))
+    src, tgt = toks.long(), toks[:, :-1].long()
+    src_mask = (src != vae.pad_idx).unsqueeze(-2)
+    tgt_mask = data_mod.make_std_mask(tgt, vae.pad_idx)
+    vae.model.eval()
+    orig = torch.randn_like
+    torch.randn_like = lambda t, *a, **k: eps.to(t.dtype)
+    try:
+        with torch.no_grad():
+            mem, mu, logvar, pred_len, enc_w = vae.model.encoder.forward_w_attn(vae.model.src_embed(src), src_mask)
+            x, fin_w, src_w = vae.model.decoder.forward_w_attn(vae.model.tgt_embed(tgt), mem, src_mask, tgt_mask)
+    finally:
+        torch.randn_like = orig
+    heads = [0, 3]
+    np.savez_compressed(os.path.join(OUT, "attn_1x128_zinc.npz"), tokens=toks.numpy().astype(np.int8),
+                        eps=eps.numpy(), heads=np.array(heads),
+                        enc=np.stack([w[:, heads].numpy() for w in enc_w]).astype(np.float16),
+                        fin=fin_w[0][:, heads].numpy().astype(np.float16),
+                        src=np.stack([w[:, heads].numpy() for w in src_w]).astype(np.float16),
+                        x_rows=x[:, :4].numpy())
+    print("attn", [tuple(w.shape) for w in enc_w], tuple(fin_w[0].shape), [tuple(w.shape) for w in src_w])
+
+
+def golden_units(tm, loss_mod, util, opt_mod):
+    rng = np.random.default_rng(21)
+    rec = {}
+    # loss on random tensors incl. an all-pad row and a NaN-KLD case (loss.py:36-37)
+    from transvae_amd import synth
+    toks = synth.synth_tokens(5, seed=1, lengths=[0, 3, 126, 50, 12])
+    logits = torch.from_numpy(rng.standard_normal((5, 126, 25)).astype(np.float32) * 3)
+    mu = torch.from_numpy(rng.standard_normal((5, 128)).astype(np.float32))
+    logvar = torch.from_numpy(rng.standard_normal((5, 128)).astype(np.float32))
+    pred_len = torch.from_numpy(rng.standard_normal((5, 128)).astype(np.float32))
+    true_len = (toks != 24).sum(-1)
+    pp = torch.from_numpy(rng.uniform(0, 1, (5, 1)).astype(np.float32))
+    tp = torch.from_numpy(rng.uniform(0, 1, 5).astype(np.float32))
+    w = torch.tensor(synth.load_vocab("zinc")[2], dtype=torch.float)
+    mu_nan = mu.clone()
+    mu_nan[1, 7] = float("nan")
+    rec["mu_nan"] = mu_nan.numpy()
+    for tag, m_in, prop in (("plain", mu, None), ("prop", mu, pp), ("nan", mu_nan, None)):
+        lv = logvar
+        ins = [t.clone().requires_grad_(True) for t in (logits, m_in, lv, pred_len)]
+        out = loss_mod.trans_vae_loss(toks, ins[0], ins[1], ins[2], true_len, ins[3], tp, prop, w, 0.3)
+        out[0].backward()
+        rec["loss_" + tag] = np.array([float(o) for o in out])
+        rec["dlogits_" + tag] = ins[0].grad.numpy()
+        rec["dmu_" + tag] = np.zeros_like(mu.numpy()) if ins[1].grad is None else ins[1].grad.numpy()
+        rec["dlogvar_" + tag] = np.zeros_like(mu.numpy()) if ins[2].grad is None else ins[2].grad.numpy()
+        rec["dpred_len_" + tag] = ins[3].grad.numpy()
+    rec.update(tokens=toks.numpy().astype(np.int8), logits=logits.numpy(), mu=mu.numpy(), logvar=logvar.numpy(),
+               pred_len=pred_len.numpy(), pred_prop=pp.numpy(), true_prop=tp.numpy(), beta=np.float64(0.3))
+    # schedules
+    ann = util.KLAnnealer(1e-8, 0.05, 100, 0)
+    rec["anneal_0_100"] = np.array([ann(e) for e in range(0, 120, 7)])
+    ann2 = util.KLAnnealer(0.001, 0.05, 60, 10)
+    rec["anneal_10_60"] = np.array([ann2(e) for e in range(0, 80, 5)])
+    no = opt_mod.NoamOpt(256, 1, 10000, torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=0))
+    steps = [1, 2, 3, 100, 9999, 10000, 10001, 50000]
+    rec["noam_steps"] = np.array(steps)
+    rec["noam_256"] = np.array([no.rate(s) for s in steps])
+    no2 = opt_mod.NoamOpt(128, 1, 10000, torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=0))
+    rec["noam_128"] = np.array([no2.rate(s) for s in steps])
+    # decode_mols
+    _, org_dict, _ = synth.load_vocab("zinc")
+    ids = torch.from_numpy(rng.integers(1, 26, (6, 125)))
+    ids[0, 10] = 25
+    ids[1, :] = 24
+    ids[2, 0] = 25
+    rec["decode_ids"] = ids.numpy().astype(np.int8)
+    rec["decode_strs"] = np.array(util.decode_mols(ids, org_dict))
+    # tokenizer + encode_smiles on real ZINC rows (reference example data; first 40)
+    import pandas as pd
+    smiles = pd.read_csv(os.path.join(REF, "notebooks/example_data/zinc_train_example.txt")).to_numpy()[:40, 1]
+    char_dict = synth.load_vocab("zinc")[0]
+    enc = np.stack([[0] + util.encode_smiles(util.tokenizer(s), 126, char_dict) for s in smiles])
+    rec["smiles"] = np.array(list(smiles))
+    rec["smiles_ids"] = enc.astype(np.int8)
+    # entropy of a fixed sample (tvae_util.py:198-204)
+    sample = rng.standard_normal((500, 6)) * np.array([0.01, 0.5, 1, 2, 3, 0.1])
+    rec["entropy_sample"] = sample
+    rec["entropy"] = util.calc_entropy(sample)
+    np.savez_compressed(os.path.join(OUT, "units.npz"), **rec)
+    print("units", rec["loss_plain"], rec["loss_nan"], rec["noam_256"][:3])
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    os.makedirs(OUT, exist_ok=True)
+    tm, loss_mod, data_mod, util, opt_mod = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "accum":
+        return golden_accum(tm, loss_mod, data_mod)
+    for name, cfg in CONFIGS.items():
+        golden_step(tm, loss_mod, data_mod, name, cfg)
+    golden_accum(tm, loss_mod, data_mod)
+    golden_decode(tm, "1x128_zinc", CONFIGS["1x128_zinc"])
+    golden_decode(tm, "4x256_zinc", CONFIGS["4x256_zinc"])
+    golden_attn(tm, data_mod)
+    golden_units(tm, loss_mod, util, opt_mod)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,245 @@
+/*
+ * tvae_kernels.h -- C ABI of libtvae_hip.so: the MI355X (gfx950) kernels under the
+ * TransVAE transformer-VAE train step and greedy decode.
+ *
+ * The reference (oriondollar/TransVAE) has no FFI / plugin interface: its hot path is a
+ * chain of stock ATen ops called from nn.Module.forward.  Each entry
+ * point below therefore cites the reference Python call site (file:line under
+ * /root/reference) whose arithmetic it replaces.  The Python host (transvae_amd/) binds
+ * these with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless
+ *     a parameter is documented as host;
+ *   - every function is asynchronous on `stream` (a hipStream_t passed as void*), never
+ *     allocates and never synchronises (the only exception is tvae_noalloc_* set-up);
+ *   - return 0 on success, a negative TVAE_E_* code otherwise; tvae_last_error() returns a
+ *     thread-local message for the last failure;
+ *   - matrices are row-major fp32; "ld" is the row stride in elements;
+ *   - `dtype`: TVAE_F32 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), TVAE_BF16 = operands
+ *     rounded to bf16 on the way into LDS, fp32 accumulate (v_mfma_f32_32x32x16_bf16);
+ *     tensors in HBM stay fp32 in both modes;
+ *   - dropout: `rng` points at two device uint32 {seed, step}; `site` names the call site;
+ *     the keep-mask is a counter-based hash of (seed, step, site, element index), so the
+ *     backward kernels regenerate it instead of storing it.  p == 0 or rng == NULL: off.
+ */
+#ifndef TVAE_KERNELS_H
+#define TVAE_KERNELS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TVAE_OK 0
+#define TVAE_E_SHAPE (-1)   /* unsupported or inconsistent shape / stride / alignment */
+#define TVAE_E_DTYPE (-2)
+#define TVAE_E_LAUNCH (-3)  /* hipGetLastError() after the launch was not hipSuccess */
+#define TVAE_E_NULL (-4)
+
+#define TVAE_F32 0
+#define TVAE_BF16 1
+
+/* gemm flags */
+#define TVAE_GEMM_RELU 1        /* v = max(v, 0) after bias */
+#define TVAE_GEMM_ACCUM 2       /* C += v instead of C = v (plain read-modify-write) */
+#define TVAE_GEMM_A_KMAJOR 4    /* A(m,k) = A[k*lda + m]  (default A[m*lda + k]) */
+#define TVAE_GEMM_B_KMAJOR 8    /* B(k,n) = B[k*ldb + n]  (default B[n*ldb + k], i.e. nn.Linear weight) */
+#define TVAE_GEMM_SPLITK 16     /* split K over grid.z, fp32 atomicAdd into C (C must be initialised) */
+#define TVAE_GEMM_RELUMASK 64   /* v = residual[m,n] > 0 ? v : 0 (`residual` is the saved activation, not added) */
+#define TVAE_GEMM_A_DROPMASK 32 /* multiply A(m,k) by the dropout keep-scale of (rng, site, m*K+k): dgrad/wgrad of a dropped-out output */
+
+const char* tvae_last_error(void);
+const char* tvae_version(void);
+
+/*
+ * C[M,N] = epilogue( alpha * sum_k A(m,k) B(k,n) ), epilogue: + bias[n] -> ReLU -> dropout(p)
+ * -> + residual[m*ldr+n].  Replaces every nn.Linear on the path
+ * (transvae/trans_models.py:747, 790, 792-793, 852, 929-930, 941, 952, 1030) together with
+ * F.relu / nn.Dropout / the residual add of SublayerConnection (:1101), their backward
+ * data- and weight-gradient products, and, via overlapping rows (lda < K), the Conv1d /
+ * ConvTranspose1d contractions of ConvBottleneck / DeconvBottleneck (:980-983, :1006-1009).
+ * Unaligned operands (ld or K not a multiple of 4) take a scalar-load path.
+ */
+int tvae_gemm(const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+              int M, int N, int K, const float* bias, const float* residual, int ldr,
+              float alpha, int flags, const uint32_t* rng, uint32_t site, float p_drop,
+              int dtype, void* stream);
+
+/* out[n] (+)= sum_m X[m*ld + n] (* dropout keep-scale if rng): bias gradients. */
+int tvae_colsum(const float* X, int ld, float* out, int M, int N, int accumulate,
+                const uint32_t* rng, uint32_t site, float p_drop, void* stream);
+
+/*
+ * LayerNorm of transvae/trans_models.py:1084-1087: y = a*(x-mean)/(std_unbiased+eps)+b.
+ * bwd: dx = dL/dx (+ add_to, if given: the residual-stream gradient of SublayerConnection,
+ * :1101) ; da, db are ACCUMULATED with atomics (caller zeroes them).
+ */
+int tvae_layernorm_fwd(const float* x, const float* a, const float* b, float* y,
+                       int rows, int d, float eps, void* stream);
+int tvae_layernorm_bwd(const float* x, const float* a, const float* dy, const float* add_to,
+                       float* dx, float* da, float* db, int rows, int d, float eps,
+                       void* stream);
+
+/*
+ * Fused multi-head attention, one workgroup per (molecule, head), score tile kept on chip.
+ * Replaces attention() (transvae/tvae_util.py:39-48) as called from
+ * MultiHeadedAttention.forward (transvae/trans_models.py:929-937): softmax(QK^T*scale with
+ * masked entries filled by -1e9) -> dropout -> PV, heads concatenated.
+ *   q: row (b, i) at q + (b*Lq + i)*ldq + head*dk ; k, v likewise with Lk ; o with ldo.
+ *   key_mask  (B, Lk) uint8 or NULL     -- the (B,1,Lk) src_mask of the reference
+ *   full_mask (B, Lq, Lk) uint8 or NULL -- an arbitrary (B,Lq,Lk) mask
+ *   causal != 0: additionally mask k > i (subsequent_mask, transvae/tvae_util.py:32-37)
+ *   lse (B, h, Lq, 2): {row max, 1 / row sum} of each score row, consumed by the backward
+ *   p_out (B, h, Lq, Lk) or NULL: the softmax weights before dropout (MultiHeadedAttention.attn,
+ *   forward_w_attn: transvae/trans_models.py:796-813, 866-880)
+ * Limits: Lq, Lk <= 128, dk in {32, 64}.
+ */
+int tvae_attn_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                  float* o, int ldo, float* lse, float* p_out,
+                  const uint8_t* key_mask, const uint8_t* full_mask, int causal,
+                  int B, int h, int Lq, int Lk, int dk, float scale,
+                  const uint32_t* rng, uint32_t site, float p_drop, int dtype, void* stream);
+/* Backward of the above.  dq/dk/dv use the same addressing as q/k/v (may be strided views);
+ * every element of the addressed head slices is written.  dsum (B, h, Lq) is workspace. */
+int tvae_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                  const float* o, int ldo, const float* d_o, int lddo, const float* lse,
+                  float* dq, int lddq, float* dk_, int lddk, float* dv, int lddv, float* dsum,
+                  const uint8_t* key_mask, const uint8_t* full_mask, int causal,
+                  int B, int h, int Lq, int Lk, int dk, float scale,
+                  const uint32_t* rng, uint32_t site, float p_drop, int dtype, void* stream);
+
+/*
+ * Embeddings + PositionalEncoding (+dropout): out[b,t,:] = lut[ids[b,t]]*sqrt(d) + pe[t,:]
+ * (transvae/trans_models.py:1042-1043, 1060-1063).  ids are int64 (torch .long()).
+ * bwd: dlut[id] += sqrt(d) * dout (atomics; caller zeroes dlut (vocab,d)).
+ */
+int tvae_embed_fwd(const int64_t* ids, const float* lut, const float* pe, float* out,
+                   int B, int L, int d, int vocab, const uint32_t* rng, uint32_t site,
+                   float p_drop, void* stream);
+int tvae_embed_bwd(const int64_t* ids, const float* dout, float* dlut, int B, int L, int d,
+                   int vocab, const uint32_t* rng, uint32_t site, float p_drop, void* stream);
+
+/*
+ * ConvBottleneck helpers (transvae/trans_models.py:976-983).  Activations are TOKEN-major
+ * (B, L, C) so that the im2col row of output position t is the contiguous slice
+ * x[b, t:t+k, :] and Conv1d becomes one tvae_gemm with lda = C, K = k*C over all B*L rows
+ * (rows whose window crosses a molecule boundary are computed and ignored).
+ *   conv weight (Cout, Cin, k) -> GEMM weight (Cout, k*Cin)           [tvae_conv_w_pack]
+ *   pool: y[b,t,c] = relu(max(conv[b,2t,c], conv[b,2t+1,c])), t < Lp = Lconv/2 ; out_cm: y is
+ *         written channel-major (B, C, Lp), the layout trans_models.py:789 flattens
+ *   pool_bwd: dconv[b,t',c] = dy routed to the arg-max element when y > 0, zero elsewhere,
+ *             for ALL rows t' < Lin (rows >= Lconv are the ignored rows: zero).
+ */
+int tvae_conv_w_pack(const float* w, float* wp, int Cout, int Cin, int k, int transposed_flip,
+                     void* stream);
+int tvae_conv_w_unpack_grad(const float* dwp, float* dw, int Cout, int Cin, int k,
+                            int transposed_flip, void* stream);
+int tvae_pool_relu_fwd(const float* conv, float* y, int B, int Lin, int Lconv, int C, int out_cm,
+                       void* stream);
+int tvae_pool_relu_bwd(const float* conv, const float* dy, float* dconv, int B, int Lin,
+                       int Lconv, int C, int dy_cm, void* stream);
+/*
+ * DeconvBottleneck helpers (transvae/trans_models.py:1001-1009).  ConvTranspose1d(k, stride s,
+ * padding p) == Conv1d with the flipped kernel over the input with s-1 zeros inserted between
+ * samples and k-1-p zeros at both ends:
+ *   up[b, lpad + s*i, c] = x[b,i,c] (lpad = k-1-p), everything else 0,
+ *   Lup = (Lin-1)*s + 1 + 2*lpad
+ * followed by tvae_gemm (weights packed with transposed_flip=1) with fused bias+ReLU.
+ *   x is token-major with src_rows rows per molecule, or channel-major (B, C, Lin) if src_cm
+ *   (the (B,64,9) view of decoder.linear's output, trans_models.py:853).  stride=1, lpad=0
+ *   compacts rows (src_rows -> Lup rows per molecule).
+ *   upsample_bwd: dx[b,t,c] = (t < Lin && (y == NULL || y[b,t,c] > 0)) ? dup[b, lpad+s*t, c] : 0
+ *   for t < dst_rows; y (ReLU mask source) and dx share a layout (token-major, or channel-major
+ *   if dst_cm).  Rows t >= Lin are zeroed: they are the rows a conv-as-GEMM ignores.
+ */
+int tvae_upsample_fwd(const float* x, int src_rows, int src_cm, float* up, int B, int Lin, int C,
+                      int stride, int lpad, int Lup, void* stream);
+int tvae_upsample_bwd(const float* dup, const float* y, float* dx, int dst_rows, int dst_cm, int B,
+                      int Lin, int C, int stride, int lpad, int Lup, void* stream);
+
+/* z = mu + eps*eps_scale*exp(0.5*logvar) (transvae/trans_models.py:771-775) and its backward
+ * (dmu += dz ; dlogvar += dz*eps*eps_scale*0.5*exp(0.5*logvar)). */
+int tvae_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z,
+                     int n, float eps_scale, void* stream);
+int tvae_reparam_bwd(const float* dz, const float* logvar, const float* eps, float* dmu,
+                     float* dlogvar, int n, float eps_scale, void* stream);
+
+/*
+ * trans_vae_loss (transvae/loss.py:23-38) forward AND backward in one pass.
+ *   tokens (B, 127) int64: targets y = tokens[:,1:]-1
+ *   true_len (B) int64 or NULL: length class per molecule; NULL = #(tokens != pad_idx), which
+ *   is what the reference passes (src_mask.sum(-1), trans_models.py:219)
+ *   logits (B*126, ldl >= 25) ; weights (25) ; pred_len (B,128) ; mu/logvar (B,dl)
+ *   pred_prop (B) / true_prop (B) or NULL
+ *   out[5] = {total, bce_mol, bce_mask, kld, mse} (written, not accumulated)
+ *   dlogits (B*126, ldl), dpred_len, dmu, dlogvar, dpred_prop: gradients of `total`
+ *   scratch: >= 8 floats of device workspace (zeroed by the call)
+ * KLD NaN guard (loss.py:36-37): if the KLD term is NaN it contributes 0 and no gradient.
+ */
+int tvae_loss_fwd_bwd(const int64_t* tokens, const float* logits, int ldl, const float* weights,
+                      const float* pred_len, const float* mu, const float* logvar,
+                      const float* pred_prop, const float* true_prop, const int64_t* true_len,
+                      float beta,
+                      int B, int L, int n_cls, int n_len, int d_latent, int pad_idx,
+                      float* out5, float* dlogits, float* dpred_len, float* dmu, float* dlogvar,
+                      float* dpred_prop, float* scratch, void* stream);
+
+/*
+ * Fused multi-tensor Adam (torch.optim.Adam as built at transvae/trans_models.py:703-705,
+ * driven by NoamOpt.step transvae/opt.py:21-30 or AdamOpt :47-49).
+ *   ptrs: device array of 4*n_tensors pointers laid out [p_0..][g_0..][m_0..][v_0..]
+ *   sizes: device int64[n_tensors]; chunk_tensor/chunk_start: device int32 tables, one entry
+ *   per 4096-element chunk (built once by the host)
+ *   hyper: device float[4] = {lr, bias_correction1, bias_correction2, grad_scale} (so a captured
+ *   graph can be replayed with a new step)
+ *   zero_grad != 0: g is zeroed after use (model.zero_grad(), trans_models.py:238)
+ */
+int tvae_adam_multi(void* const* ptrs, const int64_t* sizes, const int32_t* chunk_tensor,
+                    const int64_t* chunk_start, int n_tensors, int n_chunks,
+                    const float* hyper, float beta1, float beta2, float eps, int zero_grad,
+                    void* stream);
+
+/*
+ * KV-cached greedy decode step kernels (replace the full-recompute loop of
+ * VAEShell.greedy_decode, transvae/trans_models.py:418-434).
+ *   decode_attn: one query row per (molecule, head) against n_keys cached rows
+ *     q (n, ldq) ; kc, vc: row (b, j) at kc + (b*Lcache + j)*ldc + head*dk ;
+ *     key_mask (n, ld_mask) uint8 or NULL: keys with a 0 byte are masked (-1e9 fill, so an
+ *     all-masked row attends uniformly exactly like the reference)
+ *   argmax_next: next[b] = 1 + first arg max_c logits[b, c] ; written to ids[b*ld_ids + col]
+ *     as int64 (torch.max tie rule, trans_models.py:429-431)
+ */
+int tvae_decode_attn(const float* q, int ldq, const float* kc, const float* vc, int ldc,
+                     int Lcache, float* o, int ldo, const uint8_t* key_mask, int ld_mask,
+                     int n_keys, int n, int h, int dk, float scale, void* stream);
+int tvae_argmax_next(const float* logits, int ldl, int n_cls, int64_t* ids, int ld_ids,
+                     int col, int n, void* stream);
+/* copy rows: dst[(b*Ldst + t)*ldd + c] = src[b*lds + c], c < width (append K/V to the cache) */
+int tvae_scatter_rows(const float* src, int lds, float* dst, int ldd, int Ldst, int t,
+                      int n, int width, void* stream);
+/* mask_len[b] = first arg max of logits (n, n_cls) as int32 (predict_mask_length, :763-769) */
+int tvae_argmax_rows(const float* logits, int ldl, int n_cls, int32_t* out, int n, void* stream);
+/* out[b,:] = lut[ids[b*ld_ids + col]]*sqrt(d) + pe[col,:]  (tgt_embed of the newest token) */
+int tvae_embed_step(const int64_t* ids, int ld_ids, int col, const float* lut, const float* pe,
+                    float* out, int n, int d, int vocab, void* stream);
+
+/*
+ * Generic residual / dropout glue for callers that use the reference's modules one by one
+ * (SublayerConnection.forward with an arbitrary sublayer, trans_models.py:1099-1101;
+ * PositionalEncoding.forward, :1060-1063):
+ *   pre_add == 0: out = (res ? res : 0) + x * keep
+ *   pre_add == 1: out = (x + res[row % res_rows, :]) * keep      (res = positional table)
+ */
+int tvae_residual_dropout(const float* x, const float* res, float* out, int rows, int N,
+                          int res_rows, int pre_add, const uint32_t* rng, uint32_t site,
+                          float p_drop, void* stream);
+
+/* bump the dropout step counter: rng[1] += 1 (one tiny launch per train step, graph-safe) */
+int tvae_rng_advance(uint32_t* rng, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,243 @@
+"""Whole-path parity on the MI355X: the TransVAE classes (HIP kernels through the C ABI) against
+(a) golden vectors captured from the real reference and (b) the float64 oracle on the same
+seeded inputs.  Tolerance: 1e-5 relative on loss and per-tensor gradient L2 (north star), tokens
+bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import CONFIGS, load, oracle_params, rel_l2  # noqa: E402
+
+
+def build(cfg_name, **extra):
+    from transvae_amd import synth
+    from transvae_amd.trans_models import TransVAE
+    cfg = CONFIGS[cfg_name]
+    cd, od, w = synth.load_vocab(cfg["vocab"])
+    params = {"CHAR_DICT": cd, "ORG_DICT": od, "CHAR_WEIGHTS": w}
+    params.update(extra)
+    vae = TransVAE(params=params, name="t_" + cfg_name, property_predictor=cfg["pp"], **synth.ARCHS[cfg["arch"]])
+    sd = synth.synth_state_dict(vae.model.state_dict(), 0)
+    vae.model.load_state_dict(sd)
+    return vae
+
+
+def run_chunk(vae, toks, props, eps, beta):
+    from transvae_amd.data import make_src_mask, make_std_mask
+    from transvae_amd.loss import trans_vae_loss
+    dev = torch.device("cuda:0")
+    src = toks.to(dev).long()
+    tgt = src[:, :-1]
+    src_mask, tgt_mask = make_src_mask(src, vae.pad_idx), make_std_mask(tgt, vae.pad_idx)
+    x_out, mu, logvar, pred_len, prop = vae.model(src, tgt, src_mask, tgt_mask, eps.to(dev))
+    true_len = src_mask.sum(dim=-1)
+    out = trans_vae_loss(src, x_out, mu, logvar, true_len, pred_len, props.to(dev), prop, vae.params["CHAR_WEIGHTS"], beta)
+    return out, (x_out, mu, logvar, pred_len, prop)
+
+
+@pytest.mark.parametrize("cfg_name", ["1x128_zinc", "4x256_zinc", "4x256_pubchem_pp"])
+def test_train_chunk_matches_reference_golden_and_oracle(cfg_name):
+    from oracle import tvae_oracle as O
+    from transvae_amd import synth
+    g = load("step_" + cfg_name)
+    vae = build(cfg_name)
+    vae.model.eval()                       # dropout off, as in the golden capture
+    toks = torch.from_numpy(g["tokens"].astype(np.int64))
+    props, eps = torch.from_numpy(g["props"]), torch.from_numpy(g["eps"])
+    out, (x_out, mu, logvar, pred_len, prop) = run_chunk(vae, toks, props, eps, float(g["beta"]))
+    out[0].backward()
+    got = np.array([float(o) for o in out])
+    # forward: loss components within 1e-5 relative of the reference (fp64 truth and its own fp32 run)
+    np.testing.assert_allclose(got, g["loss_f64"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(got, g["loss_f32"], rtol=1e-5, atol=1e-7)
+    assert rel_l2(mu.detach().cpu(), g["mu"]) < 1e-5
+    assert rel_l2(logvar.detach().cpu(), g["logvar"]) < 1e-5
+    assert rel_l2(pred_len.detach().cpu(), g["pred_len"]) < 1e-5
+    assert rel_l2(x_out.detach().cpu()[[0, 2, 5]], g["logits_rows"]) < 1e-5
+    if "pred_prop" in g.files:
+        assert rel_l2(prop.detach().cpu(), g["pred_prop"]) < 1e-5
+    # backward.  Bar: per-tensor relative L2 vs the fp64 truth
+    #   * >= 90 % of the tensors within 1e-5 (north star), median below 2e-6;
+    #   * every tensor within max(3e-5, 5x the reference's OWN fp32 rounding error on that tensor
+    #     (its fp32 run vs its fp64 run, stored in the golden)).  The tensors above 1e-5 are the
+    #     source-attention query/key projections and the LayerNorm in front of them: with the
+    #     near-uniform attention of these weights dS = P (dP - sum P dP) cancels 2-3 digits in ANY
+    #     fp32 implementation -- the reference's own fp32 error there is 0.4-1.1e-5.
+    #   * key-projection biases have an exactly-zero true gradient (softmax shift invariance):
+    #     absolute bound.
+    named = dict(vae.model.named_parameters())
+    keys = [str(k) for k in g["grad_keys"]]
+    assert set(keys) == set(named)
+    ref_err = {k: float(e) for k, e in zip(keys, g["grad_ref_f32_relerr"])}
+    tol = {k: max(3e-5, 5.0 * ref_err[k]) for k in keys}
+    # (1) reference summaries: gradient norm of every tensor
+    for i, k in enumerate(keys):
+        gr = named[k].grad.detach().cpu().double().numpy().ravel()
+        nrm = g["grad_norm_f64"][i]
+        if nrm < 1e-10:
+            assert np.linalg.norm(gr) < 1e-6, k
+        else:
+            assert abs(np.linalg.norm(gr) - nrm) < tol[k] * nrm, (k, np.linalg.norm(gr), nrm, tol[k])
+    for name in g.files:
+        if name.startswith("grad_full/"):
+            k = name[len("grad_full/"):]
+            assert rel_l2(named[k].grad.cpu(), g[name]) < tol[k], k
+    # (2) per-tensor relative L2 against the float64 oracle (itself pinned to the reference)
+    P = oracle_params(cfg_name, torch.float64, requires_grad=True)
+    w = torch.tensor(synth.load_vocab(CONFIGS[cfg_name]["vocab"])[2], dtype=torch.float64)
+    losses, _ = O.chunk_loss(P, toks, props.double(), w, float(g["beta"]), eps=eps.double())
+    losses[0].backward()
+    errs = {}
+    for k in keys:
+        ref = P[k].grad.numpy()
+        if np.linalg.norm(ref) < 1e-10:
+            continue
+        errs[k] = rel_l2(named[k].grad.cpu(), ref)
+    worst = max(errs, key=errs.get)
+    n_tight = sum(e < 1e-5 for e in errs.values())
+    print("grad rel-L2 vs fp64 oracle [%s]: median %.2e, worst %.2e (%s; reference's own fp32 error there %.2e), "
+          "%d/%d tensors within 1e-5" % (cfg_name, float(np.median(list(errs.values()))), errs[worst], worst,
+                                         ref_err[worst], n_tight, len(errs)))
+    for k, e in sorted(errs.items(), key=lambda kv: -kv[1])[:14]:
+        print("    %-55s mine %.2e   reference fp32 %.2e" % (k, e, ref_err[k]))
+    for k, e in errs.items():
+        assert e < tol[k], (k, e, tol[k])
+    assert n_tight >= 0.9 * len(errs), (n_tight, len(errs))
+    assert float(np.median(list(errs.values()))) < 2e-6
+
+
+def test_accumulation_noam_adam_matches_reference():
+    g = load("accum_1x128_zinc")
+    vae = build("1x128_zinc", WARMUP_STEPS=int(g["warmup"]), BATCH_CHUNKS=2, BATCH_SIZE=12)
+    vae.model.eval()
+    named = dict(vae.model.named_parameters())
+    p0 = {str(k): named[str(k)].detach().cpu().numpy().copy() for k in g["keys"]}
+    idx = 0
+    for step in range(1, 4):
+        toks = torch.from_numpy(np.concatenate([g["tokens"][idx], g["tokens"][idx + 1]]).astype(np.float32))
+        data = torch.cat([toks, torch.zeros(12, 1)], 1)              # (12, 128): tokens | property
+        eps = torch.from_numpy(np.concatenate([g["eps"][idx], g["eps"][idx + 1]])).cuda()
+        table = vae.train_step(data, float(g["beta"]), eps=eps).cpu().numpy()
+        np.testing.assert_allclose(table[:, 0], g["losses"][idx:idx + 2], rtol=2e-5)
+        assert abs(vae.optimizer.state_dict["rate"] - g["rates"][step - 1]) < 1e-15
+        idx += 2
+        if step in (1, 3):
+            for k in g["keys"]:
+                ref = g["p_step%d/%s" % (step, k)]
+                got = named[str(k)].detach().cpu().numpy()
+                assert rel_l2(got - p0[str(k)], ref - p0[str(k)]) < 2e-3, (step, k)
+    for p in vae.model.parameters():          # gradients were reset inside the fused Adam launch
+        assert float(p.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("cfg_name", ["1x128_zinc", "4x256_zinc"])
+def test_greedy_decode_tokens_bit_exact(cfg_name):
+    g = load("decode_" + cfg_name)
+    vae = build(cfg_name)
+    z = torch.from_numpy(g["z"])
+    lens = vae.model.encoder.predict_mask_length(z.cuda())
+    assert np.array_equal(lens.cpu().numpy()[:, 0], g["mask_len"].astype(np.int64))
+    ids = vae.greedy_decode(z)
+    assert ids.dtype == torch.int64 and tuple(ids.shape) == (32, 125)
+    bad = (ids.cpu().numpy() != g["ids"].astype(np.int64))
+    assert not bad.any(), "mismatch at %s, margins there %s" % (np.argwhere(bad)[:5], g["margins"][bad][:5])
+    ids_c = vae.greedy_decode(z[:8], condition=[str(c) for c in g["cond"]])
+    assert np.array_equal(ids_c.cpu().numpy(), g["ids_cond"].astype(np.int64))
+    lens_e = torch.from_numpy(g["mask_lens_explicit"].astype(np.int64))
+    sm = (torch.arange(127)[None, :] < lens_e[:, None]).float().unsqueeze(1)
+    ids_m = vae.greedy_decode(z[8:16], src_mask=sm)
+    assert np.array_equal(ids_m.cpu().numpy(), g["ids_mask"].astype(np.int64))
+    # strings: same post-processing as the reference's decode_mols
+    from oracle import tvae_oracle as O
+    from transvae_amd.tvae_util import decode_mols
+    assert decode_mols(ids, vae.params["ORG_DICT"]) == O.decode_mols(torch.from_numpy(g["ids"].astype(np.int64)), vae.params["ORG_DICT"])
+
+
+def test_reference_style_decode_loop_matches_cached_decoder():
+    """model.decode(mem, src_mask, decoded, subsequent_mask(i)) -- the reference's own loop body --
+    must agree with the KV-cached path token for token (a few steps, small batch)."""
+    from transvae_amd.tvae_util import subsequent_mask
+    vae = build("1x128_zinc")
+    vae.model.eval()
+    g = load("decode_1x128_zinc")
+    z = torch.from_numpy(g["z"][:4]).cuda()
+    lens = vae.model.encoder.predict_mask_length(z)
+    src_mask = (torch.arange(127, device="cuda")[None, :] < lens).float().unsqueeze(1)
+    decoded = torch.zeros(4, 1, dtype=torch.long, device="cuda")
+    with torch.no_grad():
+        for i in range(12):
+            out = vae.model.generator(vae.model.decode(z, src_mask, decoded, subsequent_mask(decoded.size(1)).long()))
+            nxt = torch.max(out[:, i, :], dim=1)[1] + 1
+            decoded = torch.cat([decoded, nxt.unsqueeze(1)], 1)
+    assert np.array_equal(decoded[:, 1:].cpu().numpy(), g["ids"][:4, :12].astype(np.int64))
+
+
+def test_attention_weight_dump_matches_reference():
+    from transvae_amd.data import make_src_mask, make_std_mask
+    g = load("attn_1x128_zinc")
+    vae = build("1x128_zinc")
+    vae.model.eval()
+    src = torch.from_numpy(g["tokens"].astype(np.int64)).cuda()
+    tgt = src[:, :-1]
+    src_mask, tgt_mask = make_src_mask(src, vae.pad_idx), make_std_mask(tgt, vae.pad_idx)
+    with torch.no_grad():
+        mem, mu, logvar, pred_len, enc_w = vae.model.encoder.forward_w_attn(vae.model.src_embed(src), src_mask,
+                                                                            torch.from_numpy(g["eps"]).cuda())
+        x, fin_w, src_w = vae.model.decoder.forward_w_attn(vae.model.tgt_embed(tgt), mem, src_mask, tgt_mask)
+    heads = g["heads"].tolist()
+    for i in range(3):
+        assert tuple(enc_w[i].shape) == (2, 4, 127, 127) and tuple(src_w[i].shape) == (2, 4, 126, 127)
+        np.testing.assert_allclose(enc_w[i][:, heads].numpy(), g["enc"][i].astype(np.float32), atol=1e-3)
+        np.testing.assert_allclose(src_w[i][:, heads].numpy(), g["src"][i].astype(np.float32), atol=1e-3)
+    np.testing.assert_allclose(fin_w[0][:, heads].numpy(), g["fin"].astype(np.float32), atol=1e-3)
+    assert rel_l2(x[:, :4].cpu(), g["x_rows"]) < 1e-5
+
+
+def test_training_mode_dropout_runs_and_learns(tmp_path):
+    """Dropout on (the reference's real training mode): losses finite, parameters move, the loss
+    goes down over a few steps on a fixed batch, checkpoint round-trips."""
+    from transvae_amd import synth, ops
+    from transvae_amd.trans_models import TransVAE
+    vae = build("1x128_zinc", WARMUP_STEPS=50, BATCH_SIZE=40, BATCH_CHUNKS=2)
+    ops.seed_rng(torch.device("cuda:0"), 7)
+    vae.model.train()
+    toks = synth.synth_tokens(40, seed=3).float()
+    data = torch.cat([toks, torch.zeros(40, 1)], 1)
+    first = None
+    for step in range(12):
+        t = vae.train_step(data, 0.01).cpu().numpy()
+        assert np.isfinite(t).all()
+        first = t[:, 0].mean() if first is None else first
+    assert t[:, 0].mean() < first
+    vae.current_state["model_state_dict"] = vae.model.state_dict()
+    vae.optimizer.sync_state_dict()
+    vae.current_state["optimizer_state_dict"] = vae.optimizer.state_dict
+    vae.current_state["epoch"] = 3
+    vae.save(vae.current_state, "unit", path=str(tmp_path))
+    path = os.path.join(str(tmp_path), "unit_%s.ckpt" % vae.name)
+    assert os.path.exists(path)
+    vae2 = TransVAE(load_fn=path)
+    assert vae2.n_epochs == 3 and vae2.params["d_model"] == 128 and vae2.name == vae.name
+    for (k1, v1), (k2, v2) in zip(vae.model.state_dict().items(), vae2.model.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1.cpu(), v2.cpu())
+    assert vae2.optimizer.state_dict["step"] == 12
+
+
+def test_generic_module_paths_agree_with_fused_paths():
+    """MultiHeadedAttention / SublayerConnection / PositionwiseFeedForward used one by one (the
+    reference's call pattern) give the same numbers as the fused sublayer Functions."""
+    vae = build("1x128_zinc")
+    vae.model.eval()
+    layer = vae.model.encoder.layers[0]
+    x = torch.randn(3, 127, 128, device="cuda", generator=torch.Generator(device="cuda").manual_seed(0))
+    mask = torch.ones(3, 1, 127, device="cuda")
+    mask[1, :, 40:] = 0
+    with torch.no_grad():
+        fused = layer(x, mask)
+        y = layer.sublayer[0](x, lambda t: layer.self_attn(t, t, t, mask))
+        y = layer.sublayer[1](y, layer.feed_forward)
+    assert rel_l2(y.cpu(), fused.cpu()) < 1e-6

@@ -27,6 +27,7 @@ def test_step_forward_and_grads_f64(cfg_name):
     np.testing.assert_allclose(got, g["loss_f64"], rtol=1e-11, atol=1e-13)
     keys = [str(k) for k in g["grad_keys"]]
     assert set(keys) == {k for k in P if not k.endswith(".pe")}
+    assert float(g["gate_margins"].min()) > 2e-6      # golden inputs were chosen gate-safe
     for i, k in enumerate(keys):
         gr = P[k].grad.numpy().ravel()
         nrm = g["grad_norm_f64"][i]

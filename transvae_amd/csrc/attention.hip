@@ -1,0 +1,381 @@
+// Fused multi-head attention for TransVAE shapes (L <= 128, dk in {32, 64}), gfx950.
+//
+// One 256-thread workgroup (4 waves) per (molecule, head).  The whole score tile lives in
+// MFMA accumulators; K and V live in LDS; nothing of size L x L ever touches HBM (unless the
+// caller asks for the attention weights).
+//
+// Orientation trick: the scores are computed TRANSPOSED, S^T = K Q^T, with the query on the
+// MFMA lane and the keys in the 16 accumulator registers (x4 key tiles).  A softmax row is
+// then 64 in-lane values + one cross-half shuffle (lane ^ 32) -- the "wavefront-shuffle
+// softmax" -- and the normalised P^T accumulators ARE the B operand of O^T = V^T P^T
+// (v_mfma_f32_32x32x2_f32 takes one fp32 per lane: B[k = lane>>5][j = lane&31]); no LDS
+// round trip, no register transposition.
+//
+// Masking follows the reference exactly (transvae/tvae_util.py:43-45): masked scores are
+// REPLACED by -1e9 (not -inf), so a fully masked row attends uniformly, and masked entries get
+// no gradient.  Keys beyond Lk (tile padding) are excluded outright.
+#include "common.h"
+
+namespace {
+
+struct AttnArgs {
+  const float *q, *k, *v, *o, *d_o, *lse_in;
+  float *o_out, *lse_out, *p_out, *dq, *dk, *dv, *dsum;
+  int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+  const uint8_t *key_mask, *full_mask;
+  int causal, B, h, Lq, Lk;
+  float scale;
+  const uint32_t* rng; uint32_t site; float p;
+};
+
+constexpr float MASK_FILL = -1e9f;
+
+template <int DK>
+__device__ inline void load_tile_to_lds(float* __restrict__ T, const float* __restrict__ src, int ld, int nrows, int tid) {
+  // T[128][DK+4] <- src rows 0..nrows-1 (DK floats each), zero beyond
+  constexpr int LS = DK + 4, F4 = DK / 4;
+  for (int f = tid; f < 128 * F4; f += 256) {
+    int row = f / F4, c = (f % F4) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < nrows) v = *reinterpret_cast<const float4*>(src + (size_t)row * ld + c);
+    *reinterpret_cast<float4*>(&T[row * LS + c]) = v;
+  }
+}
+
+template <int HALF>
+__device__ inline void load_row_half(float (&reg)[HALF], const float* __restrict__ rowp, bool valid) {
+#pragma unroll
+  for (int s = 0; s < HALF; s += 4) {
+    float4 v = valid ? *reinterpret_cast<const float4*>(rowp + s) : make_float4(0.f, 0.f, 0.f, 0.f);
+    reg[s] = v.x; reg[s + 1] = v.y; reg[s + 2] = v.z; reg[s + 3] = v.w;
+  }
+}
+
+// acc[i] (+)= sum over this k-tile of A_lds[row][hh*HALF + s] * breg[s]   (32 rows x 32 lanes)
+template <int DK>
+__device__ inline floatx16 mma_rows_x_reg(const float* __restrict__ T, int row, int hh, const float (&breg)[DK / 2]) {
+  constexpr int LS = DK + 4, HALF = DK / 2;
+  floatx16 acc = zero16();
+  const float* p = &T[row * LS + hh * HALF];
+#pragma unroll
+  for (int s = 0; s < HALF; s += 4) {
+    float4 a = *reinterpret_cast<const float4*>(p + s);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, breg[s + 0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, breg[s + 1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, breg[s + 2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, breg[s + 3], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// out[u] += sum_i  T[(row0 + crow(i,hh))][32u + r] * breg[i]   (contraction over the 32 rows of a tile)
+template <int DK>
+__device__ inline void mma_cols_x_acc(floatx16 (&out)[DK / 32], const float* __restrict__ T, int row0, int hh, int r,
+                                      const floatx16& breg) {
+  constexpr int LS = DK + 4;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float* p = &T[(row0 + crow(i, hh)) * LS + r];
+#pragma unroll
+    for (int u = 0; u < DK / 32; ++u)
+      out[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[32 * u], breg[i], out[u], 0, 0, 0);
+  }
+}
+
+template <int DK>
+__device__ inline void store_rowmajor(float* __restrict__ rowp, const floatx16 (&acc)[DK / 32], int hh) {
+  // acc[u][4g+e] = value for column 32u + 8g + 4hh + e of this lane's row
+#pragma unroll
+  for (int u = 0; u < DK / 32; ++u)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 v = make_float4(acc[u][4 * g], acc[u][4 * g + 1], acc[u][4 * g + 2], acc[u][4 * g + 3]);
+      *reinterpret_cast<float4*>(rowp + 32 * u + 8 * g + 4 * hh) = v;
+    }
+}
+
+__device__ inline bool mask_bit(const AttnArgs& a, int b, int qi, int key, const uint8_t* kmask_s) {
+  bool m = kmask_s[key] != 0;
+  if (a.causal) m = m && (key <= qi);
+  if (a.full_mask) m = m && (a.full_mask[((size_t)b * a.Lq + qi) * a.Lk + key] != 0);
+  return m;
+}
+
+// ------------------------------------------------------------------------------- forward
+template <int DK>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+  constexpr int LS = DK + 4, HALF = DK / 2, NU = DK / 32;
+  __shared__ __attribute__((aligned(16))) float Ks[128 * LS];
+  __shared__ __attribute__((aligned(16))) float Vs[128 * LS];
+  __shared__ uint8_t kmask_s[128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.x / a.h, head = blockIdx.x % a.h;
+  const int qi = 32 * wave + r;
+  const bool qvalid = qi < a.Lq;
+
+  load_tile_to_lds<DK>(Ks, a.k + (size_t)b * a.Lk * a.ldk + head * DK, a.ldk, a.Lk, tid);
+  load_tile_to_lds<DK>(Vs, a.v + (size_t)b * a.Lk * a.ldv + head * DK, a.ldv, a.Lk, tid);
+  if (tid < 128) kmask_s[tid] = (tid < a.Lk) ? (a.key_mask ? a.key_mask[(size_t)b * a.Lk + tid] : 1) : 0;
+  float qreg[HALF];
+  load_row_half<HALF>(qreg, a.q + ((size_t)b * a.Lq + (qvalid ? qi : 0)) * a.ldq + head * DK + hh * HALF, qvalid);
+  __syncthreads();
+
+  DropCfg dc = drop_cfg(a.rng, a.site, a.p);
+  floatx16 st[4];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    st[t] = mma_rows_x_reg<DK>(Ks, 32 * t + r, hh, qreg);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      int key = 32 * t + crow(i, hh);
+      float s;
+      if (key >= a.Lk) s = -INFINITY;
+      else s = mask_bit(a, b, qvalid ? qi : 0, key, kmask_s) ? st[t][i] * a.scale : MASK_FILL;
+      st[t][i] = s;
+      mx = fmaxf(mx, s);
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float p = expf(st[t][i] - mx);
+      st[t][i] = p;
+      sum += p;
+    }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.f / sum;
+  const size_t prow = ((size_t)(b * a.h + head) * a.Lq + qi);
+  if (qvalid && hh == 0 && a.lse_out) {
+    // (row max, 1 / row sum) kept apart: with the -1e9 fill, max + log(sum) would round the log
+    // away in fp32 (a fully masked row would come back as P = 1 instead of 1/Lk), and
+    // exp(s - max) * inv reproduces the forward's P bit for bit in the backward kernels
+    a.lse_out[2 * prow] = mx;
+    a.lse_out[2 * prow + 1] = inv;
+  }
+
+  floatx16 oacc[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) oacc[u] = zero16();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      int key = 32 * t + crow(i, hh);
+      float p = st[t][i] * inv;
+      if (a.p_out && qvalid && key < a.Lk) a.p_out[prow * a.Lk + key] = p;
+      if (dc.on) p *= drop_scale(dc, (uint32_t)(prow * a.Lk + key));
+      st[t][i] = p;
+    }
+    mma_cols_x_acc<DK>(oacc, Vs, 32 * t, hh, r, st[t]);
+  }
+  if (qvalid) store_rowmajor<DK>(a.o_out + ((size_t)b * a.Lq + qi) * a.ldo + head * DK, oacc, hh);
+}
+
+// ------------------------------------------------------------------------------- backward: dQ
+// Same orientation as the forward (query on the lane).  Two passes over the key tiles:
+//   pass 1: P (kept in registers) and dP -> dsum = sum_j P_j dP_j / sum_j P_j
+//   pass 2: dP again -> dS = P (dP - dsum) -> dQ^T += K^T dS^T
+// dsum is formed from the SAME P and dP values that enter dS, so sum_j dS_j vanishes to rounding.
+// (The flash-attention shortcut dsum = rowsum(dO * O) is the same number mathematically, but its
+// rounding error is common to every key of the row and gets multiplied by the MEAN key; with the
+// near-uniform source attention of this model that error was 3-4x the reference's own.)
+template <int DK>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+  constexpr int LS = DK + 4, HALF = DK / 2, NU = DK / 32;
+  __shared__ __attribute__((aligned(16))) float Ks[128 * LS];
+  __shared__ __attribute__((aligned(16))) float Vs[128 * LS];
+  __shared__ uint8_t kmask_s[128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.x / a.h, head = blockIdx.x % a.h;
+  const int qi = 32 * wave + r;
+  const bool qvalid = qi < a.Lq;
+  const int qs = qvalid ? qi : 0;
+
+  load_tile_to_lds<DK>(Ks, a.k + (size_t)b * a.Lk * a.ldk + head * DK, a.ldk, a.Lk, tid);
+  load_tile_to_lds<DK>(Vs, a.v + (size_t)b * a.Lk * a.ldv + head * DK, a.ldv, a.Lk, tid);
+  if (tid < 128) kmask_s[tid] = (tid < a.Lk) ? (a.key_mask ? a.key_mask[(size_t)b * a.Lk + tid] : 1) : 0;
+  float qreg[HALF], doreg[HALF];
+  load_row_half<HALF>(qreg, a.q + ((size_t)b * a.Lq + qs) * a.ldq + head * DK + hh * HALF, qvalid);
+  load_row_half<HALF>(doreg, a.d_o + ((size_t)b * a.Lq + qs) * a.lddo + head * DK + hh * HALF, qvalid);
+  const size_t prow = ((size_t)(b * a.h + head) * a.Lq + qi);
+  const float row_mx = qvalid ? a.lse_in[2 * prow] : 0.f;
+  const float row_ls = qvalid ? a.lse_in[2 * prow + 1] : 0.f;
+  __syncthreads();
+
+  DropCfg dc = drop_cfg(a.rng, a.site, a.p);
+  floatx16 pt[4];
+  float dsum = 0.f, psum = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    floatx16 s = mma_rows_x_reg<DK>(Ks, 32 * t + r, hh, qreg);
+    floatx16 dp = mma_rows_x_reg<DK>(Vs, 32 * t + r, hh, doreg);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      int key = 32 * t + crow(i, hh);
+      float p = 0.f;
+      if (key < a.Lk && qvalid) {
+        float sc = mask_bit(a, b, qi, key, kmask_s) ? s[i] * a.scale : MASK_FILL;
+        p = expf(sc - row_mx) * row_ls;
+        psum += p;
+        dsum += p * (dp[i] * drop_scale(dc, (uint32_t)(prow * a.Lk + key)));
+      }
+      pt[t][i] = p;
+    }
+  }
+  dsum += __shfl_xor(dsum, 32, 64);
+  psum += __shfl_xor(psum, 32, 64);
+  // normalise by the ACTUAL sum of the P values used below, so that sum_j dS_j = 0 to rounding
+  dsum = qvalid ? dsum / psum : 0.f;
+  if (qvalid && hh == 0) a.dsum[prow] = dsum;
+
+  floatx16 dqacc[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) dqacc[u] = zero16();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    floatx16 dp = mma_rows_x_reg<DK>(Vs, 32 * t + r, hh, doreg);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      int key = 32 * t + crow(i, hh);
+      float ds = 0.f;
+      if (key < a.Lk && qvalid && mask_bit(a, b, qi, key, kmask_s))
+        ds = pt[t][i] * (dp[i] * drop_scale(dc, (uint32_t)(prow * a.Lk + key)) - dsum) * a.scale;
+      dp[i] = ds;
+    }
+    mma_cols_x_acc<DK>(dqacc, Ks, 32 * t, hh, r, dp);
+  }
+  if (qvalid) store_rowmajor<DK>(a.dq + ((size_t)b * a.Lq + qi) * a.lddq + head * DK, dqacc, hh);
+}
+
+// ------------------------------------------------------------------------------- backward: dK, dV
+// Key on the lane: S = Q K^T and dP = dO V^T come out as [query regs][key lanes], which is the
+// B operand of dV^T = dO^T P and dK^T = Q^T dS directly.
+template <int DK>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+  constexpr int LS = DK + 4, HALF = DK / 2, NU = DK / 32;
+  __shared__ __attribute__((aligned(16))) float Qs[128 * LS];
+  __shared__ __attribute__((aligned(16))) float Gs[128 * LS];   // dO
+  __shared__ float mx_s[128], ls_s[128], dsum_s[128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.x / a.h, head = blockIdx.x % a.h;
+  const int key = 32 * wave + r;
+  const bool kvalid = key < a.Lk;
+  const int ks = kvalid ? key : 0;
+
+  load_tile_to_lds<DK>(Qs, a.q + (size_t)b * a.Lq * a.ldq + head * DK, a.ldq, a.Lq, tid);
+  load_tile_to_lds<DK>(Gs, a.d_o + (size_t)b * a.Lq * a.lddo + head * DK, a.lddo, a.Lq, tid);
+  if (tid < 128) {
+    size_t prow = ((size_t)(b * a.h + head) * a.Lq + tid);
+    mx_s[tid] = tid < a.Lq ? a.lse_in[2 * prow] : 0.f;
+    ls_s[tid] = tid < a.Lq ? a.lse_in[2 * prow + 1] : 0.f;
+    dsum_s[tid] = tid < a.Lq ? a.dsum[prow] : 0.f;
+  }
+  float kreg[HALF], vreg[HALF];
+  load_row_half<HALF>(kreg, a.k + ((size_t)b * a.Lk + ks) * a.ldk + head * DK + hh * HALF, kvalid);
+  load_row_half<HALF>(vreg, a.v + ((size_t)b * a.Lk + ks) * a.ldv + head * DK + hh * HALF, kvalid);
+  const bool kbit = kvalid && (a.key_mask ? a.key_mask[(size_t)b * a.Lk + key] != 0 : true);
+  __syncthreads();
+
+  DropCfg dc = drop_cfg(a.rng, a.site, a.p);
+  floatx16 dkacc[NU], dvacc[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) { dkacc[u] = zero16(); dvacc[u] = zero16(); }
+#pragma unroll 1
+  for (int t = 0; t < 4; ++t) {
+    floatx16 s = mma_rows_x_reg<DK>(Qs, 32 * t + r, hh, kreg);
+    floatx16 dp = mma_rows_x_reg<DK>(Gs, 32 * t + r, hh, vreg);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      int qi = 32 * t + crow(i, hh);
+      float pt = 0.f, ds = 0.f;
+      if (kvalid && qi < a.Lq) {
+        bool m = kbit;
+        if (a.causal) m = m && (key <= qi);
+        if (a.full_mask) m = m && (a.full_mask[((size_t)b * a.Lq + qi) * a.Lk + key] != 0);
+        float sc = m ? s[i] * a.scale : MASK_FILL;
+        float p = expf(sc - mx_s[qi]) * ls_s[qi];
+        size_t prow = ((size_t)(b * a.h + head) * a.Lq + qi);
+        float ksc = drop_scale(dc, (uint32_t)(prow * a.Lk + key));
+        pt = p * ksc;
+        if (m) ds = p * (dp[i] * ksc - dsum_s[qi]) * a.scale;
+      }
+      s[i] = pt;
+      dp[i] = ds;
+    }
+    mma_cols_x_acc<DK>(dvacc, Gs, 32 * t, hh, r, s);
+    mma_cols_x_acc<DK>(dkacc, Qs, 32 * t, hh, r, dp);
+  }
+  if (kvalid) {
+    store_rowmajor<DK>(a.dk + ((size_t)b * a.Lk + key) * a.lddk + head * DK, dkacc, hh);
+    store_rowmajor<DK>(a.dv + ((size_t)b * a.Lk + key) * a.lddv + head * DK, dvacc, hh);
+  }
+}
+
+int check_common(const char* who, int B, int h, int Lq, int Lk, int dk, const int* lds, int nld, const void* const* ptrs,
+                 int nptr) {
+  TVAE_CHECK(B > 0 && h > 0 && Lq >= 1 && Lk >= 1 && Lq <= 128 && Lk <= 128, TVAE_E_SHAPE,
+             "%s: need 1 <= Lq,Lk <= 128 (got %d,%d), B=%d h=%d", who, Lq, Lk, B, h);
+  TVAE_CHECK(dk == 32 || dk == 64, TVAE_E_SHAPE, "%s: dk=%d unsupported (32 or 64)", who, dk);
+  for (int i = 0; i < nld; ++i)
+    TVAE_CHECK(lds[i] % 4 == 0 && lds[i] >= h * dk, TVAE_E_SHAPE, "%s: leading dimension %d must be a multiple of 4 and >= h*dk", who, lds[i]);
+  for (int i = 0; i < nptr; ++i)
+    TVAE_CHECK(ptrs[i] && aligned16(ptrs[i]), TVAE_E_NULL, "%s: operand %d is null or not 16-byte aligned", who, i);
+  TVAE_CHECK((long)B * h * Lq * Lk < (1L << 32), TVAE_E_SHAPE, "%s: dropout index space exceeds 32 bits", who);
+  return TVAE_OK;
+}
+
+}  // namespace
+
+extern "C" int tvae_attn_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
+                             float* lse, float* p_out, const uint8_t* key_mask, const uint8_t* full_mask, int causal,
+                             int B, int h, int Lq, int Lk, int dk, float scale, const uint32_t* rng, uint32_t site,
+                             float p_drop, int dtype, void* stream) {
+  int lds[] = {ldq, ldk, ldv, ldo};
+  const void* ptrs[] = {q, k, v, o};
+  int rc = check_common("tvae_attn_fwd", B, h, Lq, Lk, dk, lds, 4, ptrs, 4);
+  if (rc) return rc;
+  TVAE_CHECK(dtype == TVAE_F32 || dtype == TVAE_BF16, TVAE_E_DTYPE, "tvae_attn_fwd: dtype %d", dtype);
+  AttnArgs a = {};
+  a.q = q; a.k = k; a.v = v; a.o_out = o; a.lse_out = lse; a.p_out = p_out;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+  a.key_mask = key_mask; a.full_mask = full_mask; a.causal = causal;
+  a.B = B; a.h = h; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.rng = rng; a.site = site; a.p = p_drop;
+  hipStream_t s = (hipStream_t)stream;
+  if (dk == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, dim3(B * h), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(attn_fwd_kernel<32>, dim3(B * h), dim3(256), 0, s, a);
+  TVAE_LAUNCH_CHECK("tvae_attn_fwd");
+  return TVAE_OK;
+}
+
+extern "C" int tvae_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
+                             int ldo, const float* d_o, int lddo, const float* lse, float* dq, int lddq, float* dk_,
+                             int lddk, float* dv, int lddv, float* dsum, const uint8_t* key_mask,
+                             const uint8_t* full_mask, int causal, int B, int h, int Lq, int Lk, int dk, float scale,
+                             const uint32_t* rng, uint32_t site, float p_drop, int dtype, void* stream) {
+  int lds[] = {ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv};
+  const void* ptrs[] = {q, k, v, o, d_o, dq, dk_, dv};
+  int rc = check_common("tvae_attn_bwd", B, h, Lq, Lk, dk, lds, 8, ptrs, 8);
+  if (rc) return rc;
+  TVAE_CHECK(lse && dsum, TVAE_E_NULL, "tvae_attn_bwd: lse / dsum workspace missing");
+  TVAE_CHECK(dtype == TVAE_F32 || dtype == TVAE_BF16, TVAE_E_DTYPE, "tvae_attn_bwd: dtype %d", dtype);
+  AttnArgs a = {};
+  a.q = q; a.k = k; a.v = v; a.o = o; a.d_o = d_o; a.lse_in = lse;
+  a.dq = dq; a.dk = dk_; a.dv = dv; a.dsum = dsum;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+  a.key_mask = key_mask; a.full_mask = full_mask; a.causal = causal;
+  a.B = B; a.h = h; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.rng = rng; a.site = site; a.p = p_drop;
+  hipStream_t s = (hipStream_t)stream;
+  if (dk == 64) {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, dim3(B * h), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, dim3(B * h), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, dim3(B * h), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, dim3(B * h), dim3(256), 0, s, a);
+  }
+  TVAE_LAUNCH_CHECK("tvae_attn_bwd");
+  return TVAE_OK;
+}

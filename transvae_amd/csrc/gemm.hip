@@ -1,0 +1,341 @@
+// tvae_gemm: LDS-tiled MFMA GEMM for gfx950 with fused epilogues.
+//
+// Tile 128x128x32 per 256-thread workgroup (4 waves as 2x2, each wave 64x64 = 2x2 MFMA
+// 32x32 tiles).  fp32 mode uses v_mfma_f32_32x32x2_f32 (an exact fp32 fma chain, 64 cycles per
+// SIMD => 157 TFLOP/s chip peak), bf16 mode rounds the operands on their way into LDS and
+// uses v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+//
+// The contraction index inside a 32-wide k-tile is PERMUTED between lane halves: lane half
+// hh owns k = 16*hh + s (s = 0..15), so each lane reads 16 contiguous floats of its row with
+// four ds_read_b128 instead of 16 strided ds_read_b32.  A and B use the same permutation, so
+// the sum is unchanged (only its order, which fp32 parity tolerates at the 1e-7 level).
+//
+// Operands whose global layout is k-contiguous are staged as [row][k] (+4 floats of padding:
+// stride 36 floats makes the b128 fragment reads bank-conflict-free); operands whose layout
+// is m-contiguous ("k-major": weight for dgrad, both operands for wgrad) are staged as
+// [k][row] (+4) and read with conflict-free ds_read_b32.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDS_KC = BK + 4;    // [row][k] stride (floats)
+constexpr int LDS_KM = BM + 4;    // [k][row] stride (floats)
+constexpr int TILE_FLOATS = BM * LDS_KC;  // 4608 >= BK*LDS_KM (4224)
+constexpr int LDS_BF = BK + 8;    // bf16 [row][k] stride (elements): 80 B rows, conflict-free b128
+
+struct GemmArgs {
+  const float* A; const float* B; float* C; const float* bias; const float* res;
+  int lda, ldb, ldc, ldr, M, N, K;
+  float alpha; int flags;
+  const uint32_t* rng; uint32_t site; float p;
+  int k_per_split;
+};
+
+__device__ inline unsigned short f2bf(float f) {
+  // round-to-nearest-even fp32 -> bf16 (the plain cast compiles to v_cvt_pk_bf16_f32 and keeps NaNs)
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, b);
+}
+
+// ---- global -> register staging of one 128x32 operand tile (4 float4 per thread) ----------
+template <bool KM, bool ALIGNED, bool DROP>
+__device__ inline void stage_load(float4 (&st)[4], const float* __restrict__ P, int ld,
+                                  int row0, int nrows, int k0, int kend, int tid,
+                                  const DropCfg& dc, int dropM, int dropK) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int f = tid + 256 * j;
+    int row, k;
+    if (!KM) { row = f >> 3; k = (f & 7) * 4; } else { k = f >> 5; row = (f & 31) * 4; }
+    int gr = row0 + row, gk = k0 + k;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ALIGNED) {
+      if (gr < nrows && gk < kend) {
+        const float* src = KM ? (P + (size_t)gk * ld + gr) : (P + (size_t)gr * ld + gk);
+        v = *reinterpret_cast<const float4*>(src);
+      }
+    } else {
+      float t[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int rr = KM ? gr + e : gr, kk = KM ? gk : gk + e;
+        t[e] = (rr < nrows && kk < kend) ? (KM ? P[(size_t)kk * ld + rr] : P[(size_t)rr * ld + kk]) : 0.f;
+      }
+      v = make_float4(t[0], t[1], t[2], t[3]);
+    }
+    if (DROP) {
+      // element (m,k) of A carries the keep-scale of the dropped-out tensor it is the gradient of
+      float* pv = reinterpret_cast<float*>(&v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int rr = KM ? gr + e : gr, kk = KM ? gk : gk + e;
+        uint32_t idx = KM ? (uint32_t)kk * (uint32_t)dropM + (uint32_t)rr
+                          : (uint32_t)rr * (uint32_t)dropK + (uint32_t)kk;
+        pv[e] *= drop_scale(dc, idx);
+      }
+    }
+    st[j] = v;
+  }
+}
+
+template <bool KM>
+__device__ inline void stage_store_f32(const float4 (&st)[4], float* __restrict__ T, int tid) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int f = tid + 256 * j;
+    if (!KM) {
+      int row = f >> 3, k = (f & 7) * 4;
+      *reinterpret_cast<float4*>(&T[row * LDS_KC + k]) = st[j];
+    } else {
+      int k = f >> 5, row = (f & 31) * 4;
+      *reinterpret_cast<float4*>(&T[k * LDS_KM + row]) = st[j];
+    }
+  }
+}
+
+template <bool KM>
+__device__ inline void stage_store_bf16(const float4 (&st)[4], unsigned short* __restrict__ T, int tid) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int f = tid + 256 * j;
+    if (!KM) {
+      int row = f >> 3, k = (f & 7) * 4;
+      ushort4 o = make_ushort4(f2bf(st[j].x), f2bf(st[j].y), f2bf(st[j].z), f2bf(st[j].w));
+      *reinterpret_cast<ushort4*>(&T[row * LDS_BF + k]) = o;
+    } else {
+      int k = f >> 5, row = (f & 31) * 4;   // transpose on the way in: bf16 tiles are always [row][k]
+      T[(row + 0) * LDS_BF + k] = f2bf(st[j].x);
+      T[(row + 1) * LDS_BF + k] = f2bf(st[j].y);
+      T[(row + 2) * LDS_BF + k] = f2bf(st[j].z);
+      T[(row + 3) * LDS_BF + k] = f2bf(st[j].w);
+    }
+  }
+}
+
+template <bool A_KM, bool B_KM, bool ALIGNED, bool BF16, bool DROP>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * TILE_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, hh = lane >> 5;
+  const int ntn = (g.N + BN - 1) / BN;
+  const int tile_n = blockIdx.x % ntn, tile_m = blockIdx.x / ntn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kbeg = blockIdx.z * g.k_per_split;
+  const int kend = min(g.K, kbeg + g.k_per_split);
+  const int nkt = (kend - kbeg + BK - 1) / BK;
+
+  DropCfg dc = drop_cfg(DROP ? g.rng : nullptr, g.site, g.p);
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
+
+  float4 sa[4], sb[4];
+  DropCfg nodrop = drop_cfg(nullptr, 0, 0.f);
+
+  auto tileA = [&](int buf) { return lds + (buf * 2 + 0) * TILE_FLOATS; };
+  auto tileB = [&](int buf) { return lds + (buf * 2 + 1) * TILE_FLOATS; };
+
+  if (nkt > 0) {
+    stage_load<A_KM, ALIGNED, DROP>(sa, g.A, g.lda, m0, g.M, kbeg, kend, tid, dc, g.M, g.K);
+    stage_load<B_KM, ALIGNED, false>(sb, g.B, g.ldb, n0, g.N, kbeg, kend, tid, nodrop, 0, 0);
+    if (BF16) {
+      stage_store_bf16<A_KM>(sa, reinterpret_cast<unsigned short*>(tileA(0)), tid);
+      stage_store_bf16<B_KM>(sb, reinterpret_cast<unsigned short*>(tileB(0)), tid);
+    } else {
+      stage_store_f32<A_KM>(sa, tileA(0), tid);
+      stage_store_f32<B_KM>(sb, tileB(0), tid);
+    }
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    const bool more = (kt + 1 < nkt);
+    if (more) {
+      int k0 = kbeg + (kt + 1) * BK;
+      stage_load<A_KM, ALIGNED, DROP>(sa, g.A, g.lda, m0, g.M, k0, kend, tid, dc, g.M, g.K);
+      stage_load<B_KM, ALIGNED, false>(sb, g.B, g.ldb, n0, g.N, k0, kend, tid, nodrop, 0, 0);
+    }
+    if (!BF16) {
+      const float* TA = tileA(buf);
+      const float* TB = tileB(buf);
+      float a[2][16], b[2][16];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int row = wm * 64 + 32 * i + r;
+        if (!A_KM) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float4 v = *reinterpret_cast<const float4*>(&TA[row * LDS_KC + 16 * hh + 4 * q]);
+            a[i][4 * q + 0] = v.x; a[i][4 * q + 1] = v.y; a[i][4 * q + 2] = v.z; a[i][4 * q + 3] = v.w;
+          }
+        } else {
+#pragma unroll
+          for (int s = 0; s < 16; ++s) a[i][s] = TA[(16 * hh + s) * LDS_KM + row];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int col = wn * 64 + 32 * j + r;
+        if (!B_KM) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float4 v = *reinterpret_cast<const float4*>(&TB[col * LDS_KC + 16 * hh + 4 * q]);
+            b[j][4 * q + 0] = v.x; b[j][4 * q + 1] = v.y; b[j][4 * q + 2] = v.z; b[j][4 * q + 3] = v.w;
+          }
+        } else {
+#pragma unroll
+          for (int s = 0; s < 16; ++s) b[j][s] = TB[(16 * hh + s) * LDS_KM + col];
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    } else {
+      const unsigned short* TA = reinterpret_cast<const unsigned short*>(tileA(buf));
+      const unsigned short* TB = reinterpret_cast<const unsigned short*>(tileB(buf));
+      bf16x8 a[2][2], b[2][2];   // [tile][k-step of 16]
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          a[i][ks] = *reinterpret_cast<const bf16x8*>(&TA[(wm * 64 + 32 * i + r) * LDS_BF + 16 * ks + 8 * hh]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          b[j][ks] = *reinterpret_cast<const bf16x8*>(&TB[(wn * 64 + 32 * j + r) * LDS_BF + 16 * ks + 8 * hh]);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], b[j][ks], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      if (BF16) {
+        stage_store_bf16<A_KM>(sa, reinterpret_cast<unsigned short*>(tileA(buf ^ 1)), tid);
+        stage_store_bf16<B_KM>(sb, reinterpret_cast<unsigned short*>(tileB(buf ^ 1)), tid);
+      } else {
+        stage_store_f32<A_KM>(sa, tileA(buf ^ 1), tid);
+        stage_store_f32<B_KM>(sb, tileB(buf ^ 1), tid);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue ----------------------------------------------------------------------------
+  const bool relu = g.flags & TVAE_GEMM_RELU, accum = g.flags & TVAE_GEMM_ACCUM;
+  const bool splitk = g.flags & TVAE_GEMM_SPLITK, relumask = g.flags & 64;
+  DropCfg de = drop_cfg((g.flags & TVAE_GEMM_A_DROPMASK) ? nullptr : g.rng, g.site, g.p);
+  const bool lead = (blockIdx.z == 0);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int col = n0 + wn * 64 + 32 * j + r;
+      if (col >= g.N) continue;
+      float bv = (g.bias && lead) ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        int row = m0 + wm * 64 + 32 * i + crow(q, hh);
+        if (row >= g.M) continue;
+        float v = acc[i][j][q] * g.alpha + bv;
+        if (splitk) {
+          atomicAdd(&g.C[(size_t)row * g.ldc + col], v);
+          continue;
+        }
+        if (relu) v = fmaxf(v, 0.f);
+        if (relumask) {
+          // backward of relu(+dropout): pass the gradient where the saved activation is > 0
+          v = (g.res[(size_t)row * g.ldr + col] > 0.f) ? v : 0.f;
+        } else {
+          v *= drop_scale(de, (uint32_t)row * (uint32_t)g.N + (uint32_t)col);
+          if (g.res) v += g.res[(size_t)row * g.ldr + col];
+        }
+        float* dst = &g.C[(size_t)row * g.ldc + col];
+        *dst = accum ? (*dst + v) : v;
+      }
+    }
+}
+
+template <bool A_KM, bool B_KM, bool ALIGNED, bool BF16>
+void launch2(const GemmArgs& g, dim3 grid, hipStream_t s, bool drop) {
+  if (drop) hipLaunchKernelGGL((gemm_kernel<A_KM, B_KM, ALIGNED, BF16, true>), grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((gemm_kernel<A_KM, B_KM, ALIGNED, BF16, false>), grid, dim3(256), 0, s, g);
+}
+template <bool A_KM, bool B_KM>
+void launch1(const GemmArgs& g, dim3 grid, hipStream_t s, bool aligned, bool bf16, bool drop) {
+  if (aligned) {
+    if (bf16) launch2<A_KM, B_KM, true, true>(g, grid, s, drop);
+    else launch2<A_KM, B_KM, true, false>(g, grid, s, drop);
+  } else {
+    if (bf16) launch2<A_KM, B_KM, false, true>(g, grid, s, drop);
+    else launch2<A_KM, B_KM, false, false>(g, grid, s, drop);
+  }
+}
+
+}  // namespace
+
+extern "C" int tvae_gemm(const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                         int M, int N, int K, const float* bias, const float* residual, int ldr,
+                         float alpha, int flags, const uint32_t* rng, uint32_t site, float p_drop,
+                         int dtype, void* stream) {
+  TVAE_CHECK(A && B && C, TVAE_E_NULL, "tvae_gemm: null operand");
+  TVAE_CHECK(M > 0 && N > 0 && K > 0, TVAE_E_SHAPE, "tvae_gemm: M,N,K must be positive (%d,%d,%d)", M, N, K);
+  TVAE_CHECK(dtype == TVAE_F32 || dtype == TVAE_BF16, TVAE_E_DTYPE, "tvae_gemm: dtype %d", dtype);
+  const bool a_km = flags & TVAE_GEMM_A_KMAJOR, b_km = flags & TVAE_GEMM_B_KMAJOR;
+  // lda / ldb may be SMALLER than the contiguous extent: overlapping rows are how the conv
+  // bottlenecks present their im2col operands (lda = C_in < K = k*C_in).  Only C must not overlap.
+  TVAE_CHECK(lda >= 1 && ldb >= 1 && ldc >= N, TVAE_E_SHAPE,
+             "tvae_gemm: leading dimension too small (lda %d ldb %d ldc %d, N %d)", lda, ldb, ldc, N);
+  TVAE_CHECK(!((flags & 64) && !residual), TVAE_E_NULL, "tvae_gemm: RELUMASK needs the saved activation");
+  TVAE_CHECK(!residual || ldr >= N, TVAE_E_SHAPE, "tvae_gemm: ldr %d < N %d", ldr, N);
+  TVAE_CHECK((long)M * N < (1L << 32) && (long)M * K < (1L << 32), TVAE_E_SHAPE,
+             "tvae_gemm: dropout index space exceeds 32 bits");
+  if (flags & TVAE_GEMM_SPLITK)
+    TVAE_CHECK(!(flags & (TVAE_GEMM_RELU | 64)) && !residual, TVAE_E_SHAPE,
+               "tvae_gemm: split-K supports bias/alpha only");
+
+  // float4 staging needs 16-byte aligned rows and a whole number of float4 along the
+  // contiguous dimension (k for row-major operands, m/n for k-major ones)
+  bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && aligned16(A) && aligned16(B) &&
+                 (a_km ? (M % 4 == 0) : (K % 4 == 0)) && (b_km ? (N % 4 == 0) : (K % 4 == 0));
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = C; g.bias = bias; g.res = residual;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.M = M; g.N = N; g.K = K;
+  g.alpha = alpha; g.flags = flags; g.rng = rng; g.site = site; g.p = p_drop;
+  int tiles = cdiv(M, BM) * cdiv(N, BN);
+  int splits = 1;
+  if (flags & TVAE_GEMM_SPLITK) {
+    int ktiles = cdiv(K, BK);
+    splits = 1024 / tiles;               // aim at ~4 workgroups per CU
+    if (splits > ktiles / 4) splits = ktiles / 4;   // keep >= 4 k-tiles per split
+    if (splits < 1) splits = 1;
+    if (splits > 65535) splits = 65535;
+    g.k_per_split = cdiv(ktiles, splits) * BK;
+    splits = cdiv(K, g.k_per_split);
+  } else {
+    g.k_per_split = cdiv(K, BK) * BK;
+  }
+  dim3 grid(tiles, 1, splits);
+  const bool drop = (flags & TVAE_GEMM_A_DROPMASK) && rng && p_drop > 0.f;
+  hipStream_t s = (hipStream_t)stream;
+  const bool bf16 = dtype == TVAE_BF16;
+  if (!a_km && !b_km) launch1<false, false>(g, grid, s, aligned, bf16, drop);
+  else if (!a_km && b_km) launch1<false, true>(g, grid, s, aligned, bf16, drop);
+  else if (a_km && b_km) launch1<true, true>(g, grid, s, aligned, bf16, drop);
+  else launch1<true, false>(g, grid, s, aligned, bf16, drop);
+  TVAE_LAUNCH_CHECK("tvae_gemm");
+  return TVAE_OK;
+}

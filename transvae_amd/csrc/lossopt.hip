@@ -1,0 +1,372 @@
+// trans_vae_loss fused forward+backward, multi-tensor Adam, and the single-token kernels of the
+// KV-cached greedy decoder.  All HBM-bound.
+#include "common.h"
+
+namespace {
+
+__device__ inline float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+  return s;
+}
+
+struct LossArgs {
+  const int64_t* tokens; const float* logits; int ldl; const float* weights; const float* pred_len;
+  const float* mu; const float* logvar; const float* pred_prop; const float* true_prop; const int64_t* true_len; float beta;
+  int B, L, n_cls, n_len, d_latent, pad_idx;
+  float *out5, *dlogits, *dpred_len, *dmu, *dlogvar, *dpred_prop, *scratch;
+};
+
+// scratch: [0] sum w[y]  [1] sum w[y]*nll  [2] sum nll_len  [3] sum (1+lv-mu^2-e^lv)  [4] sum (pp-tp)^2
+__global__ __launch_bounds__(256) void loss_reduce_kernel(LossArgs a) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  float den = 0.f, num = 0.f;
+  const int rows = a.B * a.L;
+  const int row = blockIdx.x * 256 + tid;
+  if (row < rows) {
+    int b = row / a.L, t = row % a.L;
+    int y = (int)a.tokens[(size_t)b * (a.L + 1) + t + 1] - 1;
+    if (y >= 0 && y < a.n_cls) {
+      const float* lg = a.logits + (size_t)row * a.ldl;
+      float mx = -INFINITY;
+      for (int c = 0; c < a.n_cls; ++c) mx = fmaxf(mx, lg[c]);
+      float se = 0.f;
+      for (int c = 0; c < a.n_cls; ++c) se += expf(lg[c] - mx);
+      float w = a.weights[y];
+      den = w;
+      num = w * (mx + logf(se) - lg[y]);
+    }
+  }
+  den = block_sum(den, red);
+  num = block_sum(num, red);
+  // length-prediction CE: one wave per molecule, molecules strided over the grid's waves
+  float nl = 0.f;
+  const int gw = blockIdx.x * 4 + (tid >> 6), nw = gridDim.x * 4;
+  for (int b = gw; b < a.B; b += nw) {
+    int cnt = 0;
+    if (a.true_len) {
+      cnt = (int)a.true_len[b];
+    } else {
+      for (int t = lane; t < a.L + 1; t += 64) cnt += (a.tokens[(size_t)b * (a.L + 1) + t] != a.pad_idx);
+      cnt = (int)wave_sum((float)cnt);
+    }
+    const float* pl = a.pred_len + (size_t)b * a.n_len;
+    float mx = -INFINITY;
+    for (int c = lane; c < a.n_len; c += 64) mx = fmaxf(mx, pl[c]);
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int c = lane; c < a.n_len; c += 64) se += expf(pl[c] - mx);
+    se = wave_sum(se);
+    int cls = cnt < 0 ? 0 : (cnt < a.n_len ? cnt : a.n_len - 1);
+    if (lane == 0) nl += mx + logf(se) - pl[cls];
+  }
+  nl = block_sum(nl, red);
+  float kl = 0.f, ms = 0.f;
+  const int nz = a.B * a.d_latent;
+  for (int i = blockIdx.x * 256 + tid; i < nz; i += gridDim.x * 256) {
+    float m = a.mu[i], lv = a.logvar[i];
+    kl += 1.f + lv - m * m - expf(lv);
+  }
+  kl = block_sum(kl, red);
+  if (a.pred_prop)
+    for (int i = blockIdx.x * 256 + tid; i < a.B; i += gridDim.x * 256) {
+      float d = a.pred_prop[i] - a.true_prop[i];
+      ms += d * d;
+    }
+  ms = block_sum(ms, red);
+  if (tid == 0) {
+    atomicAdd(&a.scratch[0], den);
+    atomicAdd(&a.scratch[1], num);
+    atomicAdd(&a.scratch[2], nl);
+    atomicAdd(&a.scratch[3], kl);
+    atomicAdd(&a.scratch[4], ms);
+  }
+}
+
+__global__ __launch_bounds__(256) void loss_grad_kernel(LossArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const float den = a.scratch[0];
+  const float bce = a.scratch[1] / den;
+  const float bmask = a.scratch[2] / a.B;
+  const int nz = a.B * a.d_latent;
+  float kld = a.beta * -0.5f * (a.scratch[3] / nz);
+  const bool kl_nan = isnan(kld);
+  if (kl_nan) kld = 0.f;
+  const float mse = a.pred_prop ? a.scratch[4] / a.B : 0.f;
+  if (blockIdx.x == 0 && tid == 0) {
+    a.out5[0] = bce + bmask + kld + mse;
+    a.out5[1] = bce; a.out5[2] = bmask; a.out5[3] = kld; a.out5[4] = mse;
+  }
+  const int rows = a.B * a.L;
+  const int row = blockIdx.x * 256 + tid;
+  if (row < rows && a.dlogits) {
+    int b = row / a.L, t = row % a.L;
+    int y = (int)a.tokens[(size_t)b * (a.L + 1) + t + 1] - 1;
+    const float* lg = a.logits + (size_t)row * a.ldl;
+    float* dl = a.dlogits + (size_t)row * a.ldl;
+    if (y >= 0 && y < a.n_cls) {
+      float mx = -INFINITY;
+      for (int c = 0; c < a.n_cls; ++c) mx = fmaxf(mx, lg[c]);
+      float se = 0.f;
+      for (int c = 0; c < a.n_cls; ++c) se += expf(lg[c] - mx);
+      float coef = a.weights[y] / den, inv = 1.f / se;
+      for (int c = 0; c < a.n_cls; ++c) dl[c] = coef * (expf(lg[c] - mx) * inv - (c == y ? 1.f : 0.f));
+    } else {
+      for (int c = 0; c < a.n_cls; ++c) dl[c] = 0.f;
+    }
+  }
+  const int gw = blockIdx.x * 4 + (tid >> 6), nw = gridDim.x * 4;
+  if (a.dpred_len)
+    for (int b = gw; b < a.B; b += nw) {
+      int cnt = 0;
+      if (a.true_len) {
+        cnt = (int)a.true_len[b];
+      } else {
+        for (int t = lane; t < a.L + 1; t += 64) cnt += (a.tokens[(size_t)b * (a.L + 1) + t] != a.pad_idx);
+        cnt = (int)wave_sum((float)cnt);
+      }
+      int cls = cnt < a.n_len ? cnt : a.n_len - 1;
+      const float* pl = a.pred_len + (size_t)b * a.n_len;
+      float mx = -INFINITY;
+      for (int c = lane; c < a.n_len; c += 64) mx = fmaxf(mx, pl[c]);
+      mx = wave_max(mx);
+      float se = 0.f;
+      for (int c = lane; c < a.n_len; c += 64) se += expf(pl[c] - mx);
+      se = wave_sum(se);
+      float inv = 1.f / (se * a.B);
+      for (int c = lane; c < a.n_len; c += 64)
+        a.dpred_len[(size_t)b * a.n_len + c] = expf(pl[c] - mx) * inv - (c == cls ? 1.f / a.B : 0.f);
+    }
+  if (a.dmu)
+    for (int i = blockIdx.x * 256 + tid; i < nz; i += gridDim.x * 256) {
+      float m = a.mu[i], lv = a.logvar[i];
+      a.dmu[i] = kl_nan ? 0.f : a.beta * m / nz;
+      a.dlogvar[i] = kl_nan ? 0.f : a.beta * -0.5f * (1.f - expf(lv)) / nz;
+    }
+  if (a.pred_prop && a.dpred_prop)
+    for (int i = blockIdx.x * 256 + tid; i < a.B; i += gridDim.x * 256)
+      a.dpred_prop[i] = 2.f * (a.pred_prop[i] - a.true_prop[i]) / a.B;
+}
+
+// ------------------------------------------------------------------------------- Adam
+__global__ __launch_bounds__(256) void adam_kernel(void* const* ptrs, const int64_t* sizes, const int32_t* chunk_tensor,
+                                                   const int64_t* chunk_start, int n_tensors, const float* hyper,
+                                                   float beta2, float omb1, float omb2, float eps, int zero_grad) {
+  const int ti = chunk_tensor[blockIdx.x];
+  const int64_t start = chunk_start[blockIdx.x];
+  const int64_t n = sizes[ti];
+  float* p = (float*)ptrs[ti];
+  float* g = (float*)ptrs[n_tensors + ti];
+  float* m = (float*)ptrs[2 * n_tensors + ti];
+  float* v = (float*)ptrs[3 * n_tensors + ti];
+  const float lr = hyper[0], bc1 = hyper[1], bc2 = hyper[2], gs = hyper[3];
+  const float step_size = lr / bc1, bc2s = sqrtf(bc2);
+  const int64_t end = (start + 4096 < n) ? start + 4096 : n;
+  for (int64_t i = start + threadIdx.x; i < end; i += 256) {
+    float gi = g[i] * gs, mi = m[i], vi = v[i];
+    mi = mi + (gi - mi) * omb1;                    // exp_avg.lerp_(grad, 1-beta1)
+    vi = vi * beta2 + omb2 * gi * gi;              // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1-beta2)
+    float denom = sqrtf(vi) / bc2s + eps;
+    p[i] = p[i] - step_size * (mi / denom);        // param.addcdiv_(exp_avg, denom, -step_size)
+    m[i] = mi; v[i] = vi;
+    if (zero_grad) g[i] = 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------- decode helpers
+constexpr float MASK_FILL = -1e9f;
+
+// one wave per (molecule, head): q (dk) against n_keys cached rows
+__global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ kc,
+                                                          const float* __restrict__ vc, int ldc, int Lcache,
+                                                          float* __restrict__ o, int ldo, const uint8_t* __restrict__ key_mask,
+                                                          int ld_mask, int n_keys, int n, int h, int dk, float scale) {
+  __shared__ float ps[4][128];
+  __shared__ float qs[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pair = blockIdx.x * 4 + wave;
+  const bool active = pair < n * h;
+  const int b = active ? pair / h : 0, head = active ? pair % h : 0;
+  if (lane < dk) qs[wave][lane] = q[(size_t)b * ldq + head * dk + lane];
+  __syncthreads();
+  float sc[2];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j2 = 0; j2 < 2; ++j2) {
+    int j = lane + 64 * j2;
+    float s = -INFINITY;
+    if (j < n_keys) {
+      const float* kr = kc + ((size_t)b * Lcache + j) * ldc + head * dk;
+      float acc = 0.f;
+      for (int c = 0; c < dk; c += 4) {
+        float4 kv = *reinterpret_cast<const float4*>(kr + c);
+        acc += kv.x * qs[wave][c] + kv.y * qs[wave][c + 1] + kv.z * qs[wave][c + 2] + kv.w * qs[wave][c + 3];
+      }
+      bool m = key_mask ? key_mask[(size_t)b * ld_mask + j] != 0 : true;
+      s = m ? acc * scale : MASK_FILL;
+    }
+    sc[j2] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = wave_max(mx);
+  float e0 = expf(sc[0] - mx), e1 = expf(sc[1] - mx);
+  float inv = 1.f / wave_sum(e0 + e1);
+  ps[wave][lane] = e0 * inv;
+  ps[wave][lane + 64] = e1 * inv;
+  __syncthreads();
+  if (active && lane < dk) {
+    const float* vr = vc + (size_t)b * Lcache * ldc + head * dk + lane;
+    float acc = 0.f;
+    for (int j = 0; j < n_keys; ++j) acc += ps[wave][j] * vr[(size_t)j * ldc];
+    o[(size_t)b * ldo + head * dk + lane] = acc;
+  }
+}
+
+__global__ void argmax_kernel(const float* __restrict__ logits, int ldl, int n_cls, int64_t* ids, int ld_ids, int col,
+                              int32_t* out32, int n, int plus) {
+  int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= n) return;
+  const float* lg = logits + (size_t)b * ldl;
+  int best = 0;
+  float bv = lg[0];
+  for (int c = 1; c < n_cls; ++c)
+    if (lg[c] > bv) { bv = lg[c]; best = c; }   // strict > keeps the FIRST maximum (torch.max rule)
+  if (ids) ids[(size_t)b * ld_ids + col] = best + plus;
+  if (out32) out32[b] = best + plus;
+}
+
+__global__ void scatter_rows_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, int Ldst,
+                                    int t, int n, int width) {
+  const int w4 = width >> 2;
+  size_t total = (size_t)n * w4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    int b = (int)(i / w4), c = (int)(i % w4) * 4;
+    *reinterpret_cast<float4*>(&dst[((size_t)b * Ldst + t) * ldd + c]) =
+        *reinterpret_cast<const float4*>(&src[(size_t)b * lds + c]);
+  }
+}
+
+__global__ void embed_step_kernel(const int64_t* __restrict__ ids, int ld_ids, int col, const float* __restrict__ lut,
+                                  const float* __restrict__ pe, float* __restrict__ out, int n, int d, int vocab, float sq) {
+  const int d4 = d >> 2;
+  size_t total = (size_t)n * d4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    int b = (int)(i / d4), c = (int)(i % d4) * 4;
+    int64_t id = ids[(size_t)b * ld_ids + col];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    float4 w = *reinterpret_cast<const float4*>(&lut[(size_t)id * d + c]);
+    float4 p = *reinterpret_cast<const float4*>(&pe[(size_t)col * d + c]);
+    *reinterpret_cast<float4*>(&out[(size_t)b * d + c]) =
+        make_float4(w.x * sq + p.x, w.y * sq + p.y, w.z * sq + p.z, w.w * sq + p.w);
+  }
+}
+
+inline int grid_for(size_t total) {
+  size_t b = (total + 255) / 256;
+  return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" int tvae_loss_fwd_bwd(const int64_t* tokens, const float* logits, int ldl, const float* weights,
+                                 const float* pred_len, const float* mu, const float* logvar, const float* pred_prop,
+                                 const float* true_prop, const int64_t* true_len, float beta, int B, int L, int n_cls, int n_len, int d_latent,
+                                 int pad_idx, float* out5, float* dlogits, float* dpred_len, float* dmu, float* dlogvar,
+                                 float* dpred_prop, float* scratch, void* stream) {
+  TVAE_CHECK(tokens && logits && weights && pred_len && mu && logvar && out5 && scratch, TVAE_E_NULL,
+             "tvae_loss_fwd_bwd: null pointer");
+  TVAE_CHECK(B > 0 && L > 0 && n_cls > 0 && n_cls <= ldl && n_len > 0 && d_latent > 0, TVAE_E_SHAPE,
+             "tvae_loss_fwd_bwd: bad shape B=%d L=%d n_cls=%d ldl=%d", B, L, n_cls, ldl);
+  TVAE_CHECK(!pred_prop || true_prop, TVAE_E_NULL, "tvae_loss_fwd_bwd: pred_prop without true_prop");
+  TVAE_CHECK((dmu == nullptr) == (dlogvar == nullptr), TVAE_E_NULL, "tvae_loss_fwd_bwd: dmu/dlogvar must come together");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(scratch, 0, 8 * sizeof(float), s) != hipSuccess) {
+    tvae_set_error("tvae_loss_fwd_bwd: memset failed");
+    return TVAE_E_LAUNCH;
+  }
+  LossArgs a = {tokens, logits, ldl, weights, pred_len, mu, logvar, pred_prop, true_prop, true_len, beta,
+                B, L, n_cls, n_len, d_latent, pad_idx, out5, dlogits, dpred_len, dmu, dlogvar, dpred_prop, scratch};
+  dim3 grid(cdiv((long)B * L, 256));
+  hipLaunchKernelGGL(loss_reduce_kernel, grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL(loss_grad_kernel, grid, dim3(256), 0, s, a);
+  TVAE_LAUNCH_CHECK("tvae_loss_fwd_bwd");
+  return TVAE_OK;
+}
+
+extern "C" int tvae_adam_multi(void* const* ptrs, const int64_t* sizes, const int32_t* chunk_tensor,
+                               const int64_t* chunk_start, int n_tensors, int n_chunks, const float* hyper,
+                               float beta1, float beta2, float eps, int zero_grad, void* stream) {
+  TVAE_CHECK(ptrs && sizes && chunk_tensor && chunk_start && hyper, TVAE_E_NULL, "tvae_adam_multi: null pointer");
+  TVAE_CHECK(n_tensors > 0 && n_chunks > 0, TVAE_E_SHAPE, "tvae_adam_multi: empty parameter list");
+  float omb1 = (float)(1.0 - (double)beta1), omb2 = (float)(1.0 - (double)beta2);
+  hipLaunchKernelGGL(adam_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, ptrs, sizes, chunk_tensor,
+                     chunk_start, n_tensors, hyper, beta2, omb1, omb2, eps, zero_grad);
+  TVAE_LAUNCH_CHECK("tvae_adam_multi");
+  return TVAE_OK;
+}
+
+extern "C" int tvae_decode_attn(const float* q, int ldq, const float* kc, const float* vc, int ldc, int Lcache, float* o,
+                                int ldo, const uint8_t* key_mask, int ld_mask, int n_keys, int n, int h, int dk,
+                                float scale, void* stream) {
+  TVAE_CHECK(q && kc && vc && o, TVAE_E_NULL, "tvae_decode_attn: null pointer");
+  TVAE_CHECK(n > 0 && h > 0 && n_keys >= 1 && n_keys <= 128 && n_keys <= Lcache && (dk == 32 || dk == 64) &&
+                 ldc % 4 == 0 && aligned16(kc) && aligned16(vc),
+             TVAE_E_SHAPE, "tvae_decode_attn: need 1<=n_keys<=128, dk in {32,64}, 16-byte aligned caches (n_keys=%d dk=%d)",
+             n_keys, dk);
+  hipLaunchKernelGGL(decode_attn_kernel, dim3(cdiv((long)n * h, 4)), dim3(256), 0, (hipStream_t)stream, q, ldq, kc, vc,
+                     ldc, Lcache, o, ldo, key_mask, ld_mask, n_keys, n, h, dk, scale);
+  TVAE_LAUNCH_CHECK("tvae_decode_attn");
+  return TVAE_OK;
+}
+
+extern "C" int tvae_argmax_next(const float* logits, int ldl, int n_cls, int64_t* ids, int ld_ids, int col, int n,
+                                void* stream) {
+  TVAE_CHECK(logits && ids && n > 0 && n_cls > 0, TVAE_E_NULL, "tvae_argmax_next: bad arguments");
+  hipLaunchKernelGGL(argmax_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, logits, ldl, n_cls, ids,
+                     ld_ids, col, (int32_t*)nullptr, n, 1);
+  TVAE_LAUNCH_CHECK("tvae_argmax_next");
+  return TVAE_OK;
+}
+extern "C" int tvae_argmax_rows(const float* logits, int ldl, int n_cls, int32_t* out, int n, void* stream) {
+  TVAE_CHECK(logits && out && n > 0 && n_cls > 0, TVAE_E_NULL, "tvae_argmax_rows: bad arguments");
+  hipLaunchKernelGGL(argmax_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, logits, ldl, n_cls,
+                     (int64_t*)nullptr, 0, 0, out, n, 0);
+  TVAE_LAUNCH_CHECK("tvae_argmax_rows");
+  return TVAE_OK;
+}
+extern "C" int tvae_scatter_rows(const float* src, int lds, float* dst, int ldd, int Ldst, int t, int n, int width,
+                                 void* stream) {
+  TVAE_CHECK(src && dst, TVAE_E_NULL, "tvae_scatter_rows: null pointer");
+  TVAE_CHECK(n > 0 && width % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0 && t >= 0 && t < Ldst && aligned16(src) && aligned16(dst),
+             TVAE_E_SHAPE, "tvae_scatter_rows: bad shape/alignment");
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid_for((size_t)n * width / 4)), dim3(256), 0, (hipStream_t)stream, src,
+                     lds, dst, ldd, Ldst, t, n, width);
+  TVAE_LAUNCH_CHECK("tvae_scatter_rows");
+  return TVAE_OK;
+}
+extern "C" int tvae_embed_step(const int64_t* ids, int ld_ids, int col, const float* lut, const float* pe, float* out,
+                               int n, int d, int vocab, void* stream) {
+  TVAE_CHECK(ids && lut && pe && out, TVAE_E_NULL, "tvae_embed_step: null pointer");
+  TVAE_CHECK(n > 0 && d % 4 == 0 && col >= 0 && col < ld_ids, TVAE_E_SHAPE, "tvae_embed_step: bad shape");
+  hipLaunchKernelGGL(embed_step_kernel, dim3(grid_for((size_t)n * d / 4)), dim3(256), 0, (hipStream_t)stream, ids,
+                     ld_ids, col, lut, pe, out, n, d, vocab, sqrtf((float)d));
+  TVAE_LAUNCH_CHECK("tvae_embed_step");
+  return TVAE_OK;
+}
+
+// ------------------------------------------------------------------------------- error string
+static thread_local char g_err[512] = "";
+void tvae_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* tvae_last_error(void) { return g_err; }
+extern "C" const char* tvae_version(void) { return "tvae-hip 0.1 (gfx950)"; }

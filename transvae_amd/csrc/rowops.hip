@@ -1,0 +1,487 @@
+// HBM-bound row kernels: LayerNorm fwd/bwd, column sums, embedding + positional encoding,
+// conv/deconv bottleneck helpers, reparameterisation.  One wave (64 lanes) per row wherever a
+// row is a feature vector; all loads are 8/16 bytes per lane and coalesced.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------- LayerNorm
+// Reference semantics (transvae/trans_models.py:1084-1087): mean over the last dim, UNBIASED
+// std (divisor d-1), eps added to std:  y = a * (x - mean) / (std + eps) + b.
+template <int NPL>  // elements per lane, d = 64 * NPL, lane owns a contiguous run
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ a,
+                                                     const float* __restrict__ b, float* __restrict__ y,
+                                                     int rows, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  constexpr int d = 64 * NPL;
+  const float* xr = x + (size_t)row * d + lane * NPL;
+  float v[NPL];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) v[i] = xr[i];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) s += v[i];
+  const float mean = wave_sum(s) * (1.f / d);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) { v[i] -= mean; ss += v[i] * v[i]; }
+  const float sd = sqrtf(wave_sum(ss) * (1.f / (d - 1)));
+  const float rinv = 1.f / (sd + eps);
+  float* yr = y + (size_t)row * d + lane * NPL;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) yr[i] = a[lane * NPL + i] * v[i] * rinv + b[lane * NPL + i];
+}
+
+// dx_i = r*(g_i - mean(g)) - xc_i * r^2 * sum_j(g_j xc_j) / ((d-1) sd),  g = dy*a, r = 1/(sd+eps)
+// da += dy * xc * r ; db += dy.  Each workgroup walks ROWS_PER_WG rows, keeps da/db partials in
+// registers, reduces the 4 waves through LDS and issues one atomic per column.
+template <int NPL>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ a,
+                                                     const float* __restrict__ dy, const float* __restrict__ add_to,
+                                                     float* __restrict__ dx, float* __restrict__ da,
+                                                     float* __restrict__ db, int rows, int rows_per_wg, float eps) {
+  constexpr int d = 64 * NPL;
+  __shared__ float red[2][4][d];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float av[NPL], pa[NPL], pb[NPL];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) { av[i] = a[lane * NPL + i]; pa[i] = 0.f; pb[i] = 0.f; }
+  const int rbeg = blockIdx.x * rows_per_wg;
+  const int rend = min(rows, rbeg + rows_per_wg);
+  for (int row = rbeg + wave; row < rend; row += 4) {
+    const size_t off = (size_t)row * d + lane * NPL;
+    float v[NPL], g[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) { v[i] = x[off + i]; g[i] = dy[off + i]; }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) s += v[i];
+    const float mean = wave_sum(s) * (1.f / d);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) { v[i] -= mean; ss += v[i] * v[i]; }
+    const float sd = sqrtf(wave_sum(ss) * (1.f / (d - 1)));
+    const float rinv = 1.f / (sd + eps);
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      pb[i] += g[i];
+      pa[i] += g[i] * v[i] * rinv;
+      g[i] *= av[i];
+      sg += g[i];
+      sgx += g[i] * v[i];
+    }
+    sg = wave_sum(sg) * (1.f / d);
+    sgx = wave_sum(sgx);
+    const float c2 = rinv * rinv * sgx / ((d - 1) * sd);
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      float o = rinv * (g[i] - sg) - v[i] * c2;
+      if (add_to) o += add_to[off + i];
+      dx[off + i] = o;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) { red[0][wave][lane * NPL + i] = pa[i]; red[1][wave][lane * NPL + i] = pb[i]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 256) {
+    float sa = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+    float sb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    atomicAdd(&da[c], sa);
+    atomicAdd(&db[c], sb);
+  }
+}
+
+// ---------------------------------------------------------------------------- column sums
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int ld, float* __restrict__ out,
+                                                     int M, int N, int rows_per_wg, const uint32_t* rng,
+                                                     uint32_t site, float p) {
+  // blockDim (64, 4): x = column within a 64-wide strip, y = row phase
+  __shared__ float red[4][64];
+  DropCfg dc = drop_cfg(rng, site, p);
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  const int rbeg = blockIdx.y * rows_per_wg, rend = min(M, rbeg + rows_per_wg);
+  float s = 0.f;
+  if (col < N)
+    for (int r = rbeg + threadIdx.y; r < rend; r += 4)
+      s += X[(size_t)r * ld + col] * drop_scale(dc, (uint32_t)r * (uint32_t)N + (uint32_t)col);
+  red[threadIdx.y][threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.y == 0 && col < N)
+    atomicAdd(&out[col], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------- embedding + PE
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ lut,
+                                                        const float* __restrict__ pe, float* __restrict__ out,
+                                                        int rows, int L, int d, int vocab, float sq,
+                                                        const uint32_t* rng, uint32_t site, float p) {
+  DropCfg dc = drop_cfg(rng, site, p);
+  const int d4 = d >> 2;
+  const size_t total = (size_t)rows * d4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    int row = (int)(i / d4), c = (int)(i % d4) * 4;
+    int64_t id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    int t = row % L;
+    float4 w = *reinterpret_cast<const float4*>(&lut[(size_t)id * d + c]);
+    float4 q = *reinterpret_cast<const float4*>(&pe[(size_t)t * d + c]);
+    uint32_t base = (uint32_t)row * (uint32_t)d + (uint32_t)c;
+    float4 o;
+    o.x = (w.x * sq + q.x) * drop_scale(dc, base + 0);
+    o.y = (w.y * sq + q.y) * drop_scale(dc, base + 1);
+    o.z = (w.z * sq + q.z) * drop_scale(dc, base + 2);
+    o.w = (w.w * sq + q.w) * drop_scale(dc, base + 3);
+    *reinterpret_cast<float4*>(&out[(size_t)row * d + c]) = o;
+  }
+}
+
+// dlut[id] += sqrt(d) * keep * dout: every workgroup reduces its slab of rows into an LDS copy
+// of the (vocab x d) table first, then adds the table to global memory once.
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dout,
+                                                        float* __restrict__ dlut, int rows, int rows_per_wg, int d,
+                                                        int vocab, float sq, const uint32_t* rng, uint32_t site, float p) {
+  extern __shared__ float tab[];   // vocab * d
+  DropCfg dc = drop_cfg(rng, site, p);
+  for (int i = threadIdx.x; i < vocab * d; i += 256) tab[i] = 0.f;
+  __syncthreads();
+  const int rbeg = blockIdx.x * rows_per_wg, rend = min(rows, rbeg + rows_per_wg);
+  for (int row = rbeg; row < rend; ++row) {
+    int64_t id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    for (int c = threadIdx.x; c < d; c += 256) {
+      float g = dout[(size_t)row * d + c] * drop_scale(dc, (uint32_t)row * (uint32_t)d + (uint32_t)c) * sq;
+      tab[id * d + c] += g;   // one thread per column: no intra-workgroup race
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < vocab * d; i += 256) {
+    float v = tab[i];
+    if (v != 0.f) atomicAdd(&dlut[i], v);
+  }
+}
+
+// ---------------------------------------------------------------------------- conv helpers
+// (Cout, Cin, k) -> (Cout, k*Cin) with wp[co][j*Cin + ci] = w[co][ci][j]          (Conv1d)
+// transposed_flip: w is (Cin, Cout, k) (ConvTranspose1d) and the taps are flipped:
+//                  wp[co][j*Cin + ci] = w[ci][co][k-1-j]
+__global__ void conv_w_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int k,
+                                   int tf, int unpack_grad) {
+  const int total = Cout * Cin * k;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    int co = i / (k * Cin), rem = i % (k * Cin), j = rem / Cin, ci = rem % Cin;
+    size_t src = tf ? ((size_t)ci * Cout + co) * k + (k - 1 - j) : ((size_t)co * Cin + ci) * k + j;
+    if (unpack_grad) wp[src] = w[i];   // here `w` is dwp (packed layout) and `wp` is dw
+    else wp[i] = w[src];
+  }
+}
+
+__global__ __launch_bounds__(256) void pool_relu_fwd_kernel(const float* __restrict__ conv, float* __restrict__ y,
+                                                            int B, int Lin, int Lp, int C, int out_cm) {
+  const int c4n = C >> 2;
+  const size_t total = (size_t)B * Lp * c4n;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    int c = (int)(i % c4n) * 4;
+    size_t bt = i / c4n;
+    int t = (int)(bt % Lp), b = (int)(bt / Lp);
+    const float* p0 = conv + ((size_t)b * Lin + 2 * t) * C + c;
+    float4 u = *reinterpret_cast<const float4*>(p0);
+    float4 v = *reinterpret_cast<const float4*>(p0 + C);
+    float4 o = make_float4(fmaxf(fmaxf(u.x, v.x), 0.f), fmaxf(fmaxf(u.y, v.y), 0.f),
+                           fmaxf(fmaxf(u.z, v.z), 0.f), fmaxf(fmaxf(u.w, v.w), 0.f));
+    if (!out_cm) {
+      *reinterpret_cast<float4*>(&y[((size_t)b * Lp + t) * C + c]) = o;
+    } else {   // channel-major (B, C, Lp): the layout the reference flattens for z_means / z_var
+      float* yb = y + (size_t)b * C * Lp + t;
+      yb[(size_t)(c + 0) * Lp] = o.x; yb[(size_t)(c + 1) * Lp] = o.y;
+      yb[(size_t)(c + 2) * Lp] = o.z; yb[(size_t)(c + 3) * Lp] = o.w;
+    }
+  }
+}
+
+// dconv over ALL Lin rows of each molecule: pooled pairs route dy to the first maximal element
+// (MaxPool1d keeps the first index on ties) when the pooled value is > 0; every other row is 0.
+__global__ __launch_bounds__(256) void pool_relu_bwd_kernel(const float* __restrict__ conv, const float* __restrict__ dy,
+                                                            float* __restrict__ dconv, int B, int Lin, int Lp, int C,
+                                                            int dy_cm) {
+  const size_t total = (size_t)B * Lin * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    int c = (int)(i % C);
+    size_t bt = i / C;
+    int t = (int)(bt % Lin), b = (int)(bt / Lin);
+    float o = 0.f;
+    int tp = t >> 1;
+    if (tp < Lp) {
+      const float* p0 = conv + ((size_t)b * Lin + 2 * tp) * C + c;
+      float u = p0[0], v = p0[C];
+      float m = fmaxf(u, v);
+      bool first = (u >= v);
+      if (m > 0.f && ((t & 1) == 0) == first)
+        o = dy_cm ? dy[((size_t)b * C + c) * Lp + tp] : dy[((size_t)b * Lp + tp) * C + c];
+    }
+    dconv[i] = o;
+  }
+}
+
+// up[b, lpad + stride*i, c] = src[b, i, c] (zero elsewhere).  src has src_rows rows per molecule
+// (token-major) or is channel-major (B, C, Lin).  stride 1 / lpad 0 is a plain row compaction.
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ src, int src_rows, int src_cm,
+                                                           float* __restrict__ up, int B, int Lin, int C, int stride,
+                                                           int lpad, int Lup) {
+  const size_t total = (size_t)B * Lup * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    int c = (int)(i % C);
+    size_t bt = i / C;
+    int t = (int)(bt % Lup), b = (int)(bt / Lup);
+    int u = t - lpad;
+    float o = 0.f;
+    if (u >= 0 && u % stride == 0 && u / stride < Lin) {
+      int si = u / stride;
+      o = src_cm ? src[((size_t)b * C + c) * Lin + si] : src[((size_t)b * src_rows + si) * C + c];
+    }
+    up[i] = o;
+  }
+}
+
+// dx[b, t, c] = (t < Lin && (y == NULL || y[b,t,c] > 0)) ? dup[b, lpad + stride*t, c] : 0 for
+// t < dst_rows (token-major) or channel-major (B, C, Lin); y shares dx's layout (ReLU mask).
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dup, const float* __restrict__ y,
+                                                           float* __restrict__ dx, int dst_rows, int dst_cm, int B,
+                                                           int Lin, int C, int stride, int lpad, int Lup) {
+  const size_t total = (size_t)B * dst_rows * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    int c, t, b;
+    if (!dst_cm) { c = (int)(i % C); size_t bt = i / C; t = (int)(bt % dst_rows); b = (int)(bt / dst_rows); }
+    else { t = (int)(i % dst_rows); size_t bc = i / dst_rows; c = (int)(bc % C); b = (int)(bc / C); }
+    float o = 0.f;
+    if (t < Lin && (y == nullptr || y[i] > 0.f)) o = dup[((size_t)b * Lup + lpad + (size_t)t * stride) * C + c];
+    dx[i] = o;
+  }
+}
+
+__global__ void reparam_kernel(const float* __restrict__ mu, const float* __restrict__ logvar, const float* __restrict__ eps,
+                               float* __restrict__ z, int n, float es) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) z[i] = mu[i] + eps[i] * es * expf(0.5f * logvar[i]);
+}
+__global__ void reparam_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ logvar,
+                                   const float* __restrict__ eps, float* __restrict__ dmu, float* __restrict__ dlogvar,
+                                   int n, float es) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    dmu[i] += dz[i];
+    dlogvar[i] += dz[i] * eps[i] * es * 0.5f * expf(0.5f * logvar[i]);
+  }
+}
+
+// pre_add == 0: out = (res ? res : 0) + x * keep      (generic SublayerConnection / nn.Dropout)
+// pre_add == 1: out = (x + res[(row % res_rows), :]) * keep   (PositionalEncoding: res = pe table)
+__global__ __launch_bounds__(256) void residual_dropout_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                               float* __restrict__ out, int rows, int N, int res_rows,
+                                                               int pre_add, const uint32_t* rng, uint32_t site, float p) {
+  DropCfg dc = drop_cfg(rng, site, p);
+  const size_t total = (size_t)rows * N;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    float ks = drop_scale(dc, (uint32_t)i);
+    float v = x[i];
+    if (pre_add) {
+      size_t row = i / N, c = i % N;
+      out[i] = (v + res[(row % res_rows) * N + c]) * ks;
+    } else {
+      out[i] = (res ? res[i] : 0.f) + v * ks;
+    }
+  }
+}
+
+__global__ void rng_advance_kernel(uint32_t* rng) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) rng[1] += 1;   // vector store path (global_store_dword)
+}
+
+inline int grid_for(size_t total) {
+  size_t b = (total + 255) / 256;
+  return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+#define LN_DISPATCH(NPL_, KERNEL, ...)                                          \
+  case NPL_: hipLaunchKernelGGL((KERNEL<NPL_>), grid, dim3(256), 0, s, __VA_ARGS__); break;
+
+extern "C" int tvae_layernorm_fwd(const float* x, const float* a, const float* b, float* y, int rows, int d,
+                                  float eps, void* stream) {
+  TVAE_CHECK(x && a && b && y, TVAE_E_NULL, "tvae_layernorm_fwd: null pointer");
+  TVAE_CHECK(rows > 0 && d % 64 == 0 && d >= 64 && d <= 512, TVAE_E_SHAPE,
+             "tvae_layernorm_fwd: d=%d must be a multiple of 64 in [64,512], rows=%d", d, rows);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(cdiv(rows, 4));
+  switch (d / 64) {
+    LN_DISPATCH(1, ln_fwd_kernel, x, a, b, y, rows, eps)
+    LN_DISPATCH(2, ln_fwd_kernel, x, a, b, y, rows, eps)
+    LN_DISPATCH(3, ln_fwd_kernel, x, a, b, y, rows, eps)
+    LN_DISPATCH(4, ln_fwd_kernel, x, a, b, y, rows, eps)
+    LN_DISPATCH(5, ln_fwd_kernel, x, a, b, y, rows, eps)
+    LN_DISPATCH(6, ln_fwd_kernel, x, a, b, y, rows, eps)
+    LN_DISPATCH(7, ln_fwd_kernel, x, a, b, y, rows, eps)
+    LN_DISPATCH(8, ln_fwd_kernel, x, a, b, y, rows, eps)
+  }
+  TVAE_LAUNCH_CHECK("tvae_layernorm_fwd");
+  return TVAE_OK;
+}
+
+extern "C" int tvae_layernorm_bwd(const float* x, const float* a, const float* dy, const float* add_to, float* dx,
+                                  float* da, float* db, int rows, int d, float eps, void* stream) {
+  TVAE_CHECK(x && a && dy && dx && da && db, TVAE_E_NULL, "tvae_layernorm_bwd: null pointer");
+  TVAE_CHECK(rows > 0 && d % 64 == 0 && d >= 64 && d <= 512, TVAE_E_SHAPE,
+             "tvae_layernorm_bwd: d=%d must be a multiple of 64 in [64,512], rows=%d", d, rows);
+  hipStream_t s = (hipStream_t)stream;
+  int rpw = 64;
+  dim3 grid(cdiv(rows, rpw));
+  switch (d / 64) {
+    LN_DISPATCH(1, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
+    LN_DISPATCH(2, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
+    LN_DISPATCH(3, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
+    LN_DISPATCH(4, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
+    LN_DISPATCH(5, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
+    LN_DISPATCH(6, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
+    LN_DISPATCH(7, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
+    LN_DISPATCH(8, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
+  }
+  TVAE_LAUNCH_CHECK("tvae_layernorm_bwd");
+  return TVAE_OK;
+}
+
+extern "C" int tvae_colsum(const float* X, int ld, float* out, int M, int N, int accumulate, const uint32_t* rng,
+                           uint32_t site, float p_drop, void* stream) {
+  TVAE_CHECK(X && out, TVAE_E_NULL, "tvae_colsum: null pointer");
+  TVAE_CHECK(M > 0 && N > 0 && ld >= N, TVAE_E_SHAPE, "tvae_colsum: bad shape M=%d N=%d ld=%d", M, N, ld);
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate) {
+    if (hipMemsetAsync(out, 0, sizeof(float) * N, s) != hipSuccess) { tvae_set_error("tvae_colsum: memset failed"); return TVAE_E_LAUNCH; }
+  }
+  int rpw = 256;
+  dim3 grid(cdiv(N, 64), cdiv(M, rpw));
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(64, 4), 0, s, X, ld, out, M, N, rpw, rng, site, p_drop);
+  TVAE_LAUNCH_CHECK("tvae_colsum");
+  return TVAE_OK;
+}
+
+extern "C" int tvae_embed_fwd(const int64_t* ids, const float* lut, const float* pe, float* out, int B, int L, int d,
+                              int vocab, const uint32_t* rng, uint32_t site, float p_drop, void* stream) {
+  TVAE_CHECK(ids && lut && pe && out, TVAE_E_NULL, "tvae_embed_fwd: null pointer");
+  TVAE_CHECK(B > 0 && L > 0 && d % 4 == 0 && vocab > 0, TVAE_E_SHAPE, "tvae_embed_fwd: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  size_t total = (size_t)B * L * (d / 4);
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, ids, lut, pe, out, B * L, L, d, vocab,
+                     sqrtf((float)d), rng, site, p_drop);
+  TVAE_LAUNCH_CHECK("tvae_embed_fwd");
+  return TVAE_OK;
+}
+
+extern "C" int tvae_embed_bwd(const int64_t* ids, const float* dout, float* dlut, int B, int L, int d, int vocab,
+                              const uint32_t* rng, uint32_t site, float p_drop, void* stream) {
+  TVAE_CHECK(ids && dout && dlut, TVAE_E_NULL, "tvae_embed_bwd: null pointer");
+  size_t lds = (size_t)vocab * d * sizeof(float);
+  TVAE_CHECK(B > 0 && L > 0 && d > 0 && lds <= 64 * 1024, TVAE_E_SHAPE,
+             "tvae_embed_bwd: vocab*d*4 = %zu bytes exceeds the 64 KiB LDS table", lds);
+  hipStream_t s = (hipStream_t)stream;
+  int rows = B * L, rpw = 128;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(cdiv(rows, rpw)), dim3(256), lds, s, ids, dout, dlut, rows, rpw, d, vocab,
+                     sqrtf((float)d), rng, site, p_drop);
+  TVAE_LAUNCH_CHECK("tvae_embed_bwd");
+  return TVAE_OK;
+}
+
+extern "C" int tvae_conv_w_pack(const float* w, float* wp, int Cout, int Cin, int k, int transposed_flip, void* stream) {
+  TVAE_CHECK(w && wp && Cout > 0 && Cin > 0 && k > 0, TVAE_E_SHAPE, "tvae_conv_w_pack: bad arguments");
+  hipLaunchKernelGGL(conv_w_pack_kernel, dim3(grid_for((size_t)Cout * Cin * k)), dim3(256), 0, (hipStream_t)stream, w, wp,
+                     Cout, Cin, k, transposed_flip, 0);
+  TVAE_LAUNCH_CHECK("tvae_conv_w_pack");
+  return TVAE_OK;
+}
+extern "C" int tvae_conv_w_unpack_grad(const float* dwp, float* dw, int Cout, int Cin, int k, int transposed_flip,
+                                       void* stream) {
+  TVAE_CHECK(dwp && dw && Cout > 0 && Cin > 0 && k > 0, TVAE_E_SHAPE, "tvae_conv_w_unpack_grad: bad arguments");
+  hipLaunchKernelGGL(conv_w_pack_kernel, dim3(grid_for((size_t)Cout * Cin * k)), dim3(256), 0, (hipStream_t)stream, dwp,
+                     dw, Cout, Cin, k, transposed_flip, 1);
+  TVAE_LAUNCH_CHECK("tvae_conv_w_unpack_grad");
+  return TVAE_OK;
+}
+
+extern "C" int tvae_pool_relu_fwd(const float* conv, float* y, int B, int Lin, int Lconv, int C, int out_cm,
+                                  void* stream) {
+  TVAE_CHECK(conv && y, TVAE_E_NULL, "tvae_pool_relu_fwd: null pointer");
+  TVAE_CHECK(B > 0 && Lconv >= 2 && Lconv <= Lin && C % 4 == 0, TVAE_E_SHAPE, "tvae_pool_relu_fwd: bad shape");
+  int Lp = Lconv / 2;
+  hipLaunchKernelGGL(pool_relu_fwd_kernel, dim3(grid_for((size_t)B * Lp * C / 4)), dim3(256), 0, (hipStream_t)stream,
+                     conv, y, B, Lin, Lp, C, out_cm);
+  TVAE_LAUNCH_CHECK("tvae_pool_relu_fwd");
+  return TVAE_OK;
+}
+extern "C" int tvae_pool_relu_bwd(const float* conv, const float* dy, float* dconv, int B, int Lin, int Lconv, int C,
+                                  int dy_cm, void* stream) {
+  TVAE_CHECK(conv && dy && dconv, TVAE_E_NULL, "tvae_pool_relu_bwd: null pointer");
+  TVAE_CHECK(B > 0 && Lconv >= 2 && Lconv <= Lin, TVAE_E_SHAPE, "tvae_pool_relu_bwd: bad shape");
+  hipLaunchKernelGGL(pool_relu_bwd_kernel, dim3(grid_for((size_t)B * Lin * C)), dim3(256), 0, (hipStream_t)stream, conv,
+                     dy, dconv, B, Lin, Lconv / 2, C, dy_cm);
+  TVAE_LAUNCH_CHECK("tvae_pool_relu_bwd");
+  return TVAE_OK;
+}
+
+extern "C" int tvae_upsample_fwd(const float* x, int src_rows, int src_cm, float* up, int B, int Lin, int C,
+                                 int stride, int lpad, int Lup, void* stream) {
+  TVAE_CHECK(x && up, TVAE_E_NULL, "tvae_upsample_fwd: null pointer");
+  TVAE_CHECK(B > 0 && stride >= 1 && lpad >= 0 && Lup >= lpad + (Lin - 1) * stride + 1 && (src_cm || src_rows >= Lin),
+             TVAE_E_SHAPE, "tvae_upsample_fwd: Lup %d / src_rows %d too small", Lup, src_rows);
+  hipLaunchKernelGGL(upsample_fwd_kernel, dim3(grid_for((size_t)B * Lup * C)), dim3(256), 0, (hipStream_t)stream, x,
+                     src_rows, src_cm, up, B, Lin, C, stride, lpad, Lup);
+  TVAE_LAUNCH_CHECK("tvae_upsample_fwd");
+  return TVAE_OK;
+}
+extern "C" int tvae_upsample_bwd(const float* dup, const float* y, float* dx, int dst_rows, int dst_cm, int B,
+                                 int Lin, int C, int stride, int lpad, int Lup, void* stream) {
+  TVAE_CHECK(dup && dx, TVAE_E_NULL, "tvae_upsample_bwd: null pointer");
+  TVAE_CHECK(B > 0 && stride >= 1 && lpad >= 0 && Lup >= lpad + (Lin - 1) * stride + 1 && dst_rows >= Lin &&
+                 (!dst_cm || dst_rows == Lin),
+             TVAE_E_SHAPE, "tvae_upsample_bwd: Lup %d / dst_rows %d inconsistent", Lup, dst_rows);
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for((size_t)B * dst_rows * C)), dim3(256), 0, (hipStream_t)stream,
+                     dup, y, dx, dst_rows, dst_cm, B, Lin, C, stride, lpad, Lup);
+  TVAE_LAUNCH_CHECK("tvae_upsample_bwd");
+  return TVAE_OK;
+}
+
+extern "C" int tvae_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, int n,
+                                float eps_scale, void* stream) {
+  TVAE_CHECK(mu && logvar && eps && z && n > 0, TVAE_E_NULL, "tvae_reparam_fwd: bad arguments");
+  hipLaunchKernelGGL(reparam_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, mu, logvar, eps, z, n,
+                     eps_scale);
+  TVAE_LAUNCH_CHECK("tvae_reparam_fwd");
+  return TVAE_OK;
+}
+extern "C" int tvae_reparam_bwd(const float* dz, const float* logvar, const float* eps, float* dmu, float* dlogvar,
+                                int n, float eps_scale, void* stream) {
+  TVAE_CHECK(dz && logvar && eps && dmu && dlogvar && n > 0, TVAE_E_NULL, "tvae_reparam_bwd: bad arguments");
+  hipLaunchKernelGGL(reparam_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dz, logvar, eps, dmu,
+                     dlogvar, n, eps_scale);
+  TVAE_LAUNCH_CHECK("tvae_reparam_bwd");
+  return TVAE_OK;
+}
+
+extern "C" int tvae_rng_advance(uint32_t* rng, void* stream) {
+  TVAE_CHECK(rng, TVAE_E_NULL, "tvae_rng_advance: null pointer");
+  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, rng);
+  TVAE_LAUNCH_CHECK("tvae_rng_advance");
+  return TVAE_OK;
+}
+
+extern "C" int tvae_residual_dropout(const float* x, const float* res, float* out, int rows, int N, int res_rows,
+                                     int pre_add, const uint32_t* rng, uint32_t site, float p_drop, void* stream) {
+  TVAE_CHECK(x && out && rows > 0 && N > 0, TVAE_E_NULL, "tvae_residual_dropout: bad arguments");
+  TVAE_CHECK(!pre_add || (res && res_rows > 0), TVAE_E_NULL, "tvae_residual_dropout: pre_add needs a table");
+  TVAE_CHECK((long)rows * N < (1L << 32), TVAE_E_SHAPE, "tvae_residual_dropout: index space exceeds 32 bits");
+  hipLaunchKernelGGL(residual_dropout_kernel, dim3(grid_for((size_t)rows * N)), dim3(256), 0, (hipStream_t)stream, x, res,
+                     out, rows, N, res_rows, pre_add, rng, site, p_drop);
+  TVAE_LAUNCH_CHECK("tvae_residual_dropout");
+  return TVAE_OK;
+}

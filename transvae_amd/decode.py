@@ -1,0 +1,93 @@
+"""KV-cached greedy decoder: replaces the O(L^2) full-recompute loop of VAEShell.greedy_decode
+(reference transvae/trans_models.py:383-436) with one memory expansion + 125 single-token steps.
+
+Per step and decoder layer: LayerNorm -> one fused QKV GEMM (M = molecules) -> append K,V to the
+cache -> one-query attention over the cache -> output projection (+residual) -> LayerNorm ->
+query projection -> one-query attention over the PRE-PROJECTED memory keys/values -> projection
+-> LayerNorm -> FFN.  The arg-max is taken on the device; token ids never visit the host.
+The arithmetic per position is the same as the reference's (causal masking makes position i
+independent of later positions), which is what makes the token sequences bit-identical.
+"""
+import math
+
+import torch
+
+from . import ops
+from .ops import _p, _stream, call
+
+
+class GreedyDecoder:
+    def __init__(self, model, h):
+        self.model, self.h = model, h
+
+    @staticmethod
+    def _ln(x, norm):
+        return ops.layernorm_fwd(x, norm.a_2, norm.b_2, norm.eps)
+
+    @torch.no_grad()
+    def run(self, z, key_mask, start_id, cond_ids=(), max_len=125):
+        """z (n, d_latent) on the device; key_mask (n, 127) uint8 source mask; returns (n, max_len) int64."""
+        model, h = self.model, self.h
+        dec = model.decoder
+        dev = z.device
+        n = z.shape[0]
+        d = dec.size
+        dk = d // h
+        scale = 1.0 / math.sqrt(dk)
+        spec = ops.MaskSpec(key_mask=key_mask)
+        mem = dec.expand_memory(z, spec)                     # (n, 127, d), already through decoder.norm
+        Ls = mem.shape[1]
+        mem2 = mem.reshape(n * Ls, d)
+        T = max_len + 1
+        layers = list(dec.layers)
+        # source-attention keys/values never change during decoding: project them once
+        kc, vc, wqkv, bqkv = [], [], [], []
+        for lyr in layers:
+            lin = lyr.src_attn.linears
+            kc.append(ops.linear_fwd(mem2, lin[1].weight, lin[1].bias))
+            vc.append(ops.linear_fwd(mem2, lin[2].weight, lin[2].bias))
+            sl = lyr.self_attn.linears
+            wqkv.append(torch.cat([sl[0].weight, sl[1].weight, sl[2].weight], 0).contiguous())
+            bqkv.append(torch.cat([sl[0].bias, sl[1].bias, sl[2].bias], 0).contiguous())
+        ks = [torch.empty((n, T, d), device=dev, dtype=torch.float32) for _ in layers]
+        vs = [torch.empty((n, T, d), device=dev, dtype=torch.float32) for _ in layers]
+        ids = torch.full((n, T), int(start_id), dtype=torch.int64, device=dev)
+        for j, t in enumerate(cond_ids):
+            ids[:, j + 1] = int(t)
+        emb, pos = model.tgt_embed[0], model.tgt_embed[1]
+        lut, pe = emb.lut.weight, pos.pe[0]
+        vocab = lut.shape[0]
+        gen = model.generator.proj
+        n_cls = gen.weight.shape[0]
+        x = torch.empty((n, d), device=dev, dtype=torch.float32)
+        qkv = torch.empty((n, 3 * d), device=dev, dtype=torch.float32)
+        att = torch.empty((n, d), device=dev, dtype=torch.float32)
+        st = _stream()
+        for t in range(max_len):
+            call("tvae_embed_step", _p(ids), T, t, _p(lut), _p(pe), _p(x), n, d, vocab, st)
+            cur = x
+            for li, lyr in enumerate(layers):
+                sub = lyr.sublayer
+                n0 = self._ln(cur, sub[0].norm)
+                ops.linear_fwd(n0, wqkv[li], bqkv[li], out=qkv)
+                call("tvae_scatter_rows", _p(qkv[:, d:]), 3 * d, _p(ks[li]), d, T, t, n, d, st)
+                call("tvae_scatter_rows", _p(qkv[:, 2 * d:]), 3 * d, _p(vs[li]), d, T, t, n, d, st)
+                call("tvae_decode_attn", _p(qkv), 3 * d, _p(ks[li]), _p(vs[li]), d, T, _p(att), d, None, 0,
+                     t + 1, n, h, dk, scale, st)
+                so = lyr.self_attn.linears[3]
+                cur = ops.linear_fwd(att, so.weight, so.bias, residual=cur)
+                n1 = self._ln(cur, sub[1].norm)
+                cl = lyr.src_attn.linears
+                q = ops.linear_fwd(n1, cl[0].weight, cl[0].bias)
+                call("tvae_decode_attn", _p(q), d, _p(kc[li]), _p(vc[li]), d, Ls, _p(att), d, _p(key_mask), Ls,
+                     Ls, n, h, dk, scale, st)
+                cur = ops.linear_fwd(att, cl[3].weight, cl[3].bias, residual=cur)
+                n2 = self._ln(cur, sub[2].norm)
+                ff = lyr.feed_forward
+                hmid = ops.linear_fwd(n2, ff.w_1.weight, ff.w_1.bias, relu=True)
+                cur = ops.linear_fwd(hmid, ff.w_2.weight, ff.w_2.bias, residual=cur)
+            if t >= len(cond_ids):
+                y = self._ln(cur, dec.norm)
+                logits = ops.linear_fwd(y, gen.weight, gen.bias)
+                call("tvae_argmax_next", _p(logits), n_cls, n_cls, _p(ids), T, t + 1, n, st)
+        return ids[:, 1:]

@@ -1,0 +1,748 @@
+"""Thin Python layer over the C ABI: raw launch helpers + block-level autograd Functions.
+
+torch is used for device memory (allocation of outputs/workspaces), the current HIP stream and
+the autograd graph that chains the block-level Functions.  Every piece of arithmetic on the
+TransVAE hot path runs in libtvae_hip.so; nothing here falls back to ATen math.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import (F32, BF16, GEMM_RELU, GEMM_ACCUM, GEMM_A_KMAJOR, GEMM_B_KMAJOR, GEMM_SPLITK,
+                   GEMM_A_DROPMASK, GEMM_RELUMASK, call)
+
+# ----------------------------------------------------------------------------- configuration
+_state = {"dtype": F32, "site": 0}
+
+
+def set_compute_dtype(name):
+    """'fp32' (exact, v_mfma_f32_32x32x2_f32) or 'bf16' (bf16 operands, fp32 accumulate)."""
+    _state["dtype"] = {"fp32": F32, "f32": F32, "bf16": BF16}[name]
+
+
+def compute_dtype():
+    return "bf16" if _state["dtype"] == BF16 else "fp32"
+
+
+def next_site():
+    _state["site"] += 1
+    return _state["site"]
+
+
+_rng = {}
+
+
+def rng_state(device):
+    """Device uint32[2] {seed, step} shared by every dropout site on `device`."""
+    key = (device.type, device.index)
+    if key not in _rng:
+        _rng[key] = torch.tensor([0x1234567, 0], dtype=torch.int32, device=device)
+    return _rng[key]
+
+
+def seed_rng(device, seed):
+    st = rng_state(device)
+    st.copy_(torch.tensor([seed & 0x7FFFFFFF, 0], dtype=torch.int32))
+
+
+def advance_rng(device):
+    call("tvae_rng_advance", _p(rng_state(device)), _stream())
+
+
+class Drop:
+    """One dropout site: probability + site id (+ the device rng).  ``off`` when p == 0."""
+    __slots__ = ("p", "site", "rng")
+
+    def __init__(self, p, site, rng):
+        self.p, self.site, self.rng = float(p), int(site), rng
+
+    @staticmethod
+    def make(p, site, training, device):
+        if not training or p <= 0.0:
+            return None
+        return Drop(p, site, rng_state(device))
+
+
+def _drop_args(drop):
+    if drop is None:
+        return None, 0, 0.0
+    return _p(drop.rng), drop.site, drop.p
+
+
+def _p(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses host tensors: handing a host address to
+    a kernel is a GPU memory fault, not an exception, so it is caught here."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.TvaeError("host tensor (shape %s, dtype %s) passed where a device buffer is required"
+                             % (tuple(t.shape), t.dtype))
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, name):
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise _lib.TvaeError("%s must be a float32 CUDA tensor (got %s on %s)" % (name, t.dtype, t.device))
+
+
+# ----------------------------------------------------------------------------- raw launchers
+def gemm(A, lda, Bm, ldb, Cm, ldc, M, N, K, bias=None, residual=None, ldr=0, alpha=1.0, flags=0,
+         drop=None, dtype=None):
+    r, s, p = _drop_args(drop)
+    call("tvae_gemm", _p(A), lda, _p(Bm), ldb, _p(Cm), ldc, M, N, K, _p(bias), _p(residual), ldr,
+         alpha, flags, r, s, p, _state["dtype"] if dtype is None else dtype, _stream())
+
+
+def linear_fwd(x, W, b=None, relu=False, residual=None, drop=None, out=None):
+    """y[M,N] = drop(relu(x W^T + b)) + residual.  x: (M,K) contiguous rows, W: (N,K)."""
+    M, K = x.shape
+    N = W.shape[0]
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    gemm(x, x.stride(0), W, W.stride(0), out, out.stride(0), M, N, K, bias=b, residual=residual,
+         ldr=0 if residual is None else residual.stride(0), flags=GEMM_RELU if relu else 0, drop=drop)
+    return out
+
+
+def linear_dgrad(dy, W, out=None, accumulate=False, relumask=None, alpha=1.0, a_drop=None):
+    """dx[M,K] (+)= (dy * keepscale) W, optionally masked by (relumask > 0).  W: (N,K)."""
+    M, N = dy.shape
+    K = W.shape[1]
+    if out is None:
+        out = torch.empty((M, K), device=dy.device, dtype=torch.float32)
+    flags = GEMM_B_KMAJOR | (GEMM_ACCUM if accumulate else 0)
+    if a_drop is not None:
+        flags |= GEMM_A_DROPMASK
+    if relumask is not None:
+        flags |= GEMM_RELUMASK
+    gemm(dy, dy.stride(0), W, W.stride(0), out, out.stride(0), M, K, N, residual=relumask,
+         ldr=0 if relumask is None else relumask.stride(0), alpha=alpha, flags=flags, drop=a_drop)
+    return out
+
+
+def linear_wgrad(dy, x, a_drop=None, want_bias=True):
+    """dW[N,K] = (dy*keepscale)^T x (split-K, fp32 atomics into zeros), db[N] = colsum."""
+    M, N = dy.shape
+    K = x.shape[1]
+    dW = torch.zeros((N, K), device=dy.device, dtype=torch.float32)
+    flags = GEMM_A_KMAJOR | GEMM_B_KMAJOR | GEMM_SPLITK | (GEMM_A_DROPMASK if a_drop is not None else 0)
+    gemm(dy, dy.stride(0), x, x.stride(0), dW, K, N, K, M, flags=flags, drop=a_drop)
+    db = colsum(dy, a_drop) if want_bias else None
+    return dW, db
+
+
+def colsum(X, drop=None):
+    M, N = X.shape
+    out = torch.zeros((N,), device=X.device, dtype=torch.float32)
+    r, s, p = _drop_args(drop)
+    call("tvae_colsum", _p(X), X.stride(0), _p(out), M, N, 1, r, s, p, _stream())
+    return out
+
+
+def layernorm_fwd(x2, a, b, eps=1e-6):
+    y = torch.empty_like(x2)
+    call("tvae_layernorm_fwd", _p(x2), _p(a), _p(b), _p(y), x2.shape[0], x2.shape[1], eps, _stream())
+    return y
+
+
+def layernorm_bwd(x2, a, dy, add_to=None, eps=1e-6):
+    dx = torch.empty_like(x2)
+    dab = torch.zeros((2, x2.shape[1]), device=x2.device, dtype=torch.float32)
+    call("tvae_layernorm_bwd", _p(x2), _p(a), _p(dy), _p(add_to), _p(dx), _p(dab[0]), _p(dab[1]),
+         x2.shape[0], x2.shape[1], eps, _stream())
+    return dx, dab[0], dab[1]
+
+
+class MaskSpec:
+    """Attention mask in kernel form: key_mask (B,Lk) uint8 and/or causal flag and/or a full
+    (B,Lq,Lk) uint8 mask.  Built by ``mask_spec`` from the reference's bool/float masks."""
+    __slots__ = ("key_mask", "causal", "full")
+
+    def __init__(self, key_mask=None, causal=False, full=None):
+        self.key_mask, self.causal, self.full = key_mask, bool(causal), full
+
+
+def tag_mask(mask, spec):
+    """Attach the kernel form to a reference-style mask tensor (so callers keep the tensor API)."""
+    mask._tvae_spec = spec
+    return mask
+
+
+def mask_spec(mask, B, Lq, Lk, device=None):
+    """Kernel form of a reference-style mask ((B|1, 1, Lk) or (B|1, Lq, Lk), zero = masked),
+    moved to `device` if it lives elsewhere (the reference builds decode masks on the host)."""
+    if mask is None:
+        return MaskSpec()
+    if isinstance(mask, MaskSpec):
+        return mask
+    spec = getattr(mask, "_tvae_spec", None)
+    if spec is not None and (device is None or all(t is None or t.device == device for t in (spec.key_mask, spec.full))):
+        return spec
+    m = mask if device is None else mask.to(device)
+    if m.dim() == 4:                    # already unsqueezed for heads
+        m = m[:, 0]
+    if m.dim() != 3:
+        raise _lib.TvaeError("attention mask must be (B,1,Lk) or (B,Lq,Lk), got %s" % (tuple(mask.shape),))
+    nz = (m != 0)
+    if m.shape[1] == 1:
+        km = nz[:, 0, :].expand(B, Lk).to(torch.uint8).contiguous()
+        return MaskSpec(key_mask=km)
+    return MaskSpec(full=nz.expand(B, Lq, Lk).to(torch.uint8).contiguous())
+
+
+def attn_fwd(q, k, v, B, h, Lq, Lk, dk, spec, drop=None, want_p=False):
+    """q: (B*Lq, >=h*dk) row views (stride(0) = ld); returns o (B*Lq, h*dk), lse, p."""
+    o = torch.empty((B * Lq, h * dk), device=q.device, dtype=torch.float32)
+    lse = torch.empty((B, h, Lq, 2), device=q.device, dtype=torch.float32)
+    p_out = torch.empty((B, h, Lq, Lk), device=q.device, dtype=torch.float32) if want_p else None
+    r, s, p = _drop_args(drop)
+    call("tvae_attn_fwd", _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
+         _p(lse), _p(p_out), _p(spec.key_mask), _p(spec.full), int(spec.causal), B, h, Lq, Lk, dk,
+         1.0 / math.sqrt(dk), r, s, p, _state["dtype"], _stream())
+    return o, lse, p_out
+
+
+def attn_bwd(q, k, v, o, do, lse, B, h, Lq, Lk, dk, spec, drop=None):
+    dq = torch.empty((B * Lq, h * dk), device=q.device, dtype=torch.float32)
+    dkk = torch.empty((B * Lk, h * dk), device=q.device, dtype=torch.float32)
+    dv = torch.empty((B * Lk, h * dk), device=q.device, dtype=torch.float32)
+    dsum = torch.empty((B, h, Lq), device=q.device, dtype=torch.float32)
+    r, s, p = _drop_args(drop)
+    call("tvae_attn_bwd", _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
+         _p(do), do.stride(0), _p(lse), _p(dq), dq.stride(0), _p(dkk), dkk.stride(0), _p(dv), dv.stride(0),
+         _p(dsum), _p(spec.key_mask), _p(spec.full), int(spec.causal), B, h, Lq, Lk, dk,
+         1.0 / math.sqrt(dk), r, s, p, _state["dtype"], _stream())
+    return dq, dkk, dv
+
+
+# ----------------------------------------------------------------------------- autograd blocks
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, a, b, eps):
+        x2 = _c(x).view(-1, x.shape[-1])
+        _chk(x2, "x")
+        y = layernorm_fwd(x2, a, b, eps)
+        ctx.save_for_backward(x2, a)
+        ctx.eps = eps
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, a = ctx.saved_tensors
+        dx, da, db = layernorm_bwd(x2, a, _c(dy).view(x2.shape), None, ctx.eps)
+        return dx.view(dy.shape), da, db, None
+
+
+def relu_mask(dy2, y):
+    """dy * [y > 0] in one pass (the stride-1 form of the upsample-backward kernel)."""
+    out = torch.empty_like(dy2)
+    M, N = dy2.shape
+    call("tvae_upsample_bwd", _p(dy2), _p(y), _p(out), M, 0, 1, M, N, 1, 0, M, _stream())
+    return out
+
+
+class LinearFn(torch.autograd.Function):
+    """y = [relu](x W^T + b): z_means / z_var / predict_len / decoder.linear / generator /
+    property-predictor layers (reference trans_models.py:747, 790-793, 852, 1030)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, relu):
+        x2 = _c(x).view(-1, x.shape[-1])
+        _chk(x2, "x")
+        y = linear_fwd(x2, W, b, relu=relu)
+        ctx.save_for_backward(x2, W, y if relu else None)
+        ctx.relu, ctx.has_bias, ctx.xshape = relu, b is not None, x.shape
+        return y.view(x.shape[:-1] + (W.shape[0],))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W, y = ctx.saved_tensors
+        dy2 = _c(dy).view(-1, W.shape[0])
+        if ctx.relu:
+            dy2 = relu_mask(dy2, y)
+        dx = linear_dgrad(dy2, W).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dW, db = linear_wgrad(dy2, x2, want_bias=ctx.has_bias)
+        return dx, dW, db, None
+
+
+class EmbedFn(torch.autograd.Function):
+    """Embeddings * sqrt(d) + PositionalEncoding (+dropout), trans_models.py:1042-1043, 1060-1063."""
+
+    @staticmethod
+    def forward(ctx, ids, lut, pe, drop):
+        B, L = ids.shape
+        vocab, d = lut.shape
+        ids = _c(ids)
+        out = torch.empty((B, L, d), device=lut.device, dtype=torch.float32)
+        r, s, p = _drop_args(drop)
+        pe2 = pe.view(-1, d)
+        if L > pe2.shape[0]:
+            raise _lib.TvaeError("sequence length %d exceeds positional table %d" % (L, pe2.shape[0]))
+        call("tvae_embed_fwd", _p(ids), _p(lut), _p(pe2), _p(out), B, L, d, vocab, r, s, p, _stream())
+        ctx.save_for_backward(ids)
+        ctx.drop, ctx.shape = drop, (vocab, d)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ids,) = ctx.saved_tensors
+        vocab, d = ctx.shape
+        B, L = ids.shape
+        dlut = torch.zeros((vocab, d), device=dout.device, dtype=torch.float32)
+        r, s, p = _drop_args(ctx.drop)
+        call("tvae_embed_bwd", _p(ids), _p(_c(dout)), _p(dlut), B, L, d, vocab, r, s, p, _stream())
+        return None, dlut, None, None
+
+
+class AttnCoreFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(dk), masked) v on (B, L, h*dk) tensors (heads are column blocks)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, spec, h, drop):
+        B, Lq, d = q.shape
+        Lk = k.shape[1]
+        dk = d // h
+        q2, k2, v2 = _c(q).view(-1, d), _c(k).view(-1, d), _c(v).view(-1, d)
+        o, lse, _ = attn_fwd(q2, k2, v2, B, h, Lq, Lk, dk, spec, drop)
+        ctx.save_for_backward(q2, k2, v2, o, lse)
+        ctx.meta = (B, h, Lq, Lk, dk, spec, drop)
+        return o.view(B, Lq, d)
+
+    @staticmethod
+    def backward(ctx, do):
+        q2, k2, v2, o, lse = ctx.saved_tensors
+        B, h, Lq, Lk, dk, spec, drop = ctx.meta
+        dq, dkk, dv = attn_bwd(q2, k2, v2, o, _c(do).view(-1, h * dk), lse, B, h, Lq, Lk, dk, spec, drop)
+        return dq.view(B, Lq, -1), dkk.view(B, Lk, -1), dv.view(B, Lk, -1), None, None, None
+
+
+def attention_weights(q, k, spec, h):
+    """P = softmax(mask(q k^T/sqrt(dk))) as (B, h, Lq, Lk) -- no gradient (forward_w_attn path)."""
+    B, Lq, d = q.shape
+    Lk = k.shape[1]
+    q2, k2 = _c(q).view(-1, d), _c(k).view(-1, d)
+    _, _, p = attn_fwd(q2, k2, k2, B, h, Lq, Lk, d // h, spec, None, want_p=True)
+    return p
+
+
+class AttnSublayerFn(torch.autograd.Function):
+    """One SublayerConnection around MultiHeadedAttention, fused end to end:
+        y = x + dropout( W_o attn( W_q LN(x), W_k m, W_v m ) + b_o ),   m = LN(x) or `mem`
+    (reference trans_models.py:1099-1101 around :921-941).  Saves x, LN(x), q, k, v, attn-out, lse.
+    """
+
+    @staticmethod
+    def forward(ctx, x, mem, ln_a, ln_b, Wq, bq, Wk, bk, Wv, bv, Wo, bo, spec, h, drop_attn, drop_res, eps):
+        B, Lq, d = x.shape
+        x2 = _c(x).view(-1, d)
+        _chk(x2, "x")
+        n = layernorm_fwd(x2, ln_a, ln_b, eps)
+        if mem is None:
+            kv_in, Lk = n, Lq
+        else:
+            kv_in, Lk = _c(mem).view(-1, d), mem.shape[1]
+        dk = d // h
+        q = linear_fwd(n, Wq, bq)
+        k = linear_fwd(kv_in, Wk, bk)
+        v = linear_fwd(kv_in, Wv, bv)
+        o, lse, _ = attn_fwd(q, k, v, B, h, Lq, Lk, dk, spec, drop_attn)
+        y = linear_fwd(o, Wo, bo, residual=x2, drop=drop_res)
+        ctx.save_for_backward(x2, n, kv_in if mem is not None else None, q, k, v, o, lse, ln_a, Wq, Wk, Wv, Wo)
+        ctx.meta = (B, h, Lq, Lk, dk, spec, drop_attn, drop_res, eps, mem is not None)
+        return y.view(B, Lq, d)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, n, memv, q, k, v, o, lse, ln_a, Wq, Wk, Wv, Wo = ctx.saved_tensors
+        B, h, Lq, Lk, dk, spec, drop_attn, drop_res, eps, cross = ctx.meta
+        d = h * dk
+        dy2 = _c(dy).view(-1, d)
+        do = linear_dgrad(dy2, Wo, a_drop=drop_res)
+        dWo, dbo = linear_wgrad(dy2, o, a_drop=drop_res)
+        dq, dkk, dv = attn_bwd(q, k, v, o, do, lse, B, h, Lq, Lk, dk, spec, drop_attn)
+        kv_in = memv if cross else n
+        dWq, dbq = linear_wgrad(dq, n)
+        dWk, dbk = linear_wgrad(dkk, kv_in)
+        dWv, dbv = linear_wgrad(dv, kv_in)
+        dn = linear_dgrad(dq, Wq)
+        if cross:
+            dmem = linear_dgrad(dkk, Wk)
+            linear_dgrad(dv, Wv, out=dmem, accumulate=True)
+            dmem = dmem.view(B, Lk, d)
+        else:
+            linear_dgrad(dkk, Wk, out=dn, accumulate=True)
+            linear_dgrad(dv, Wv, out=dn, accumulate=True)
+            dmem = None
+        dx, da, db = layernorm_bwd(x2, ln_a, dn, add_to=dy2, eps=eps)
+        return (dx.view(B, Lq, d), dmem, da, db, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo,
+                None, None, None, None, None)
+
+
+class FFNSublayerFn(torch.autograd.Function):
+    """y = x + dropout( W_2 dropout(relu(W_1 LN(x) + b_1)) + b_2 )  (trans_models.py:951-952, 1101)."""
+
+    @staticmethod
+    def forward(ctx, x, ln_a, ln_b, W1, b1, W2, b2, drop_ff, drop_res, eps):
+        shp = x.shape
+        x2 = _c(x).view(-1, shp[-1])
+        _chk(x2, "x")
+        n = layernorm_fwd(x2, ln_a, ln_b, eps)
+        hmid = linear_fwd(n, W1, b1, relu=True, drop=drop_ff)
+        y = linear_fwd(hmid, W2, b2, residual=x2, drop=drop_res)
+        ctx.save_for_backward(x2, n, hmid, ln_a, W1, W2)
+        ctx.meta = (drop_ff, drop_res, eps, shp)
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, n, hmid, ln_a, W1, W2 = ctx.saved_tensors
+        drop_ff, drop_res, eps, shp = ctx.meta
+        dy2 = _c(dy).view(x2.shape)
+        dW2, db2 = linear_wgrad(dy2, hmid, a_drop=drop_res)
+        # hmid = keepscale * relu(pre): hmid > 0 <=> kept and pre > 0, so one mask + one scale
+        sc = 1.0 / (1.0 - drop_ff.p) if drop_ff is not None else 1.0
+        dh = linear_dgrad(dy2, W2, relumask=hmid, alpha=sc, a_drop=drop_res)
+        dW1, db1 = linear_wgrad(dh, n)
+        dn = linear_dgrad(dh, W1)
+        dx, da, db = layernorm_bwd(x2, ln_a, dn, add_to=dy2, eps=eps)
+        return dx.view(shp), da, db, dW1, db1, dW2, db2, None, None, None
+
+
+class ReparamFn(torch.autograd.Function):
+    """z = mu + eps * eps_scale * exp(0.5 logvar)  (trans_models.py:771-775)."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, eps, eps_scale):
+        mu, logvar, eps = _c(mu), _c(logvar), _c(eps)
+        z = torch.empty_like(mu)
+        call("tvae_reparam_fwd", _p(mu), _p(logvar), _p(eps), _p(z), mu.numel(), float(eps_scale), _stream())
+        ctx.save_for_backward(logvar, eps)
+        ctx.eps_scale = float(eps_scale)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        logvar, eps = ctx.saved_tensors
+        dmu = torch.zeros_like(logvar)
+        dlv = torch.zeros_like(logvar)
+        call("tvae_reparam_bwd", _p(_c(dz)), _p(logvar), _p(eps), _p(dmu), _p(dlv), logvar.numel(),
+             ctx.eps_scale, _stream())
+        return dmu, dlv, None, None
+
+
+# ----------------------------------------------------------------------------- conv / deconv
+def _pack_w(w, rows, inner, k, tf):
+    """(rows, inner*k)-shaped GEMM weight from a conv kernel tensor, see tvae_conv_w_pack."""
+    wp = torch.empty((rows, k * inner), device=w.device, dtype=torch.float32)
+    call("tvae_conv_w_pack", _p(w), _p(wp), rows, inner, k, int(tf), _stream())
+    return wp
+
+
+def _unpack_dw(dwp, shape, Cout, Cin, k, tf):
+    dw = torch.empty(shape, device=dwp.device, dtype=torch.float32)
+    call("tvae_conv_w_unpack_grad", _p(dwp), _p(dw), Cout, Cin, k, int(tf), _stream())
+    return dw
+
+
+def _conv_gemm(xin, rows_total, Cin, wp, bias, k, relu):
+    """out[r, :] = act(sum_j x[r+j, :] . wp[:, j*Cin:(j+1)*Cin] + bias) for r < rows_total-(k-1);
+    xin is the flat (rows_total, Cin) token-major buffer (im2col rows overlap: lda = Cin)."""
+    Cout = wp.shape[0]
+    out = torch.empty((rows_total, Cout), device=xin.device, dtype=torch.float32)
+    gemm(xin, Cin, wp, k * Cin, out, Cout, rows_total - (k - 1), Cout, k * Cin, bias=bias,
+         flags=GEMM_RELU if relu else 0)
+    return out
+
+
+def _conv_wgrad(dy_rows, xin, rows_total, Cin, Cout, k):
+    """dwp[co, j*Cin+ci] = sum_r dy[r, co] x[r+j, ci] over r < rows_total-(k-1) (split-K atomics)."""
+    dwp = torch.zeros((Cout, k * Cin), device=xin.device, dtype=torch.float32)
+    gemm(dy_rows, Cout, xin, Cin, dwp, k * Cin, Cout, k * Cin, rows_total - (k - 1),
+         flags=GEMM_A_KMAJOR | GEMM_B_KMAJOR | GEMM_SPLITK)
+    return dwp
+
+
+def _conv_dgrad(dy_padded, rows_total, Cout, w_dgrad, Cin, k):
+    """dx[u, ci] = sum_j dy[u-j, :] . w[:, ci, j]: a conv-as-GEMM over the gradient rows.
+    dy_padded is ((k-1) + rows_total, Cout) with k-1 leading zero rows; w_dgrad is (Cin, k*Cout)."""
+    dx = torch.empty((rows_total, Cin), device=dy_padded.device, dtype=torch.float32)
+    gemm(dy_padded, Cout, w_dgrad, k * Cout, dx, Cin, rows_total, Cin, k * Cout)
+    return dx
+
+
+class ConvBottleneckFn(torch.autograd.Function):
+    """ConvBottleneck (trans_models.py:976-983): 3 x relu(MaxPool1d(2)(Conv1d)), token-major.
+    Input (B, L, C0); output (B, 64*9) in the reference's channel-major flattening (:789)."""
+
+    @staticmethod
+    def forward(ctx, x, W0, b0, W1, b1, W2, b2):
+        B, L, C = x.shape
+        cur = _c(x).view(B * L, C)
+        _chk(cur, "x")
+        saved, metas = [], []
+        for li, (W, b) in enumerate(((W0, b0), (W1, b1), (W2, b2))):
+            Cout, Cin, k = W.shape
+            wp = _pack_w(W, Cout, Cin, k, False)
+            conv = _conv_gemm(cur, B * L, Cin, wp, b, k, relu=False)
+            Lconv = L - k + 1
+            Lp = Lconv // 2
+            last = li == 2
+            y = torch.empty((B, Cout, Lp) if last else (B * Lp, Cout), device=x.device, dtype=torch.float32)
+            call("tvae_pool_relu_fwd", _p(conv), _p(y), B, L, Lconv, Cout, int(last), _stream())
+            saved += [cur, conv]
+            metas.append((L, Lconv, Lp, Cin, Cout, k))
+            cur, L = y, Lp
+        ctx.save_for_backward(W0, W1, W2, *saved)
+        ctx.metas, ctx.B = metas, B
+        return cur.view(B, -1)
+
+    @staticmethod
+    def backward(ctx, dout):
+        W = ctx.saved_tensors[:3]
+        saved = ctx.saved_tensors[3:]
+        B = ctx.B
+        dy = _c(dout)
+        grads = [None] * 6
+        for li in (2, 1, 0):
+            L, Lconv, Lp, Cin, Cout, k = ctx.metas[li]
+            xin, conv = saved[2 * li], saved[2 * li + 1]
+            buf = torch.zeros(((k - 1) + B * L, Cout), device=dy.device, dtype=torch.float32)
+            dconv = buf[k - 1:]
+            call("tvae_pool_relu_bwd", _p(conv), _p(dy), _p(dconv), B, L, Lconv, Cout, int(li == 2), _stream())
+            dwp = _conv_wgrad(dconv, xin, B * L, Cin, Cout, k)
+            grads[2 * li] = _unpack_dw(dwp, W[li].shape, Cout, Cin, k, False)
+            grads[2 * li + 1] = colsum(dconv)
+            if li > 0 or ctx.needs_input_grad[0]:
+                wd = _pack_w(W[li], Cin, Cout, k, True)       # (Cin, k*Cout): wd[ci][j*Cout+co] = W[co][ci][k-1-j]
+                dy = _conv_dgrad(buf, B * L, Cout, wd, Cin, k)
+        dx = dy.view(B, ctx.metas[0][0], ctx.metas[0][3]) if ctx.needs_input_grad[0] else None
+        return (dx,) + tuple(grads)
+
+
+class DeconvBottleneckFn(torch.autograd.Function):
+    """DeconvBottleneck (trans_models.py:1001-1009): 3 x relu(ConvTranspose1d(k=11, stride, pad 2)).
+    Input (B, 576) = the (B,64,9) view of relu(decoder.linear(z)) (:852-853); output (B, 127, d)."""
+    STRIDES = (4, 3, 1)
+    PAD = 2
+
+    @staticmethod
+    def forward(ctx, hlin, W0, b0, W1, b1, W2, b2):
+        B = hlin.shape[0]
+        src = _c(hlin)
+        _chk(src, "hlin")
+        Lin, src_rows, src_cm = hlin.shape[1] // W0.shape[0], 0, 1
+        saved, metas = [], []
+        for li, (W, b) in enumerate(((W0, b0), (W1, b1), (W2, b2))):
+            Cin, Cout, k = W.shape
+            s, lpad = DeconvBottleneckFn.STRIDES[li], k - 1 - DeconvBottleneckFn.PAD
+            Lout = (Lin - 1) * s - 2 * DeconvBottleneckFn.PAD + k
+            Lup = Lout + k - 1
+            up = torch.empty((B * Lup, Cin), device=src.device, dtype=torch.float32)
+            call("tvae_upsample_fwd", _p(src), src_rows, src_cm, _p(up), B, Lin, Cin, s, lpad, Lup, _stream())
+            wp = _pack_w(W, Cout, Cin, k, True)                          # flipped taps, (Cout, k*Cin)
+            y = _conv_gemm(up, B * Lup, Cin, wp, b, k, relu=True)        # (B*Lup, Cout), rows t < Lout valid
+            saved += [up, y]
+            metas.append((Lin, Lout, Lup, Cin, Cout, k, s, lpad))
+            src, Lin, src_rows, src_cm = y, Lout, Lup, 0
+        Cd = metas[2][4]
+        out = torch.empty((B, Lin, Cd), device=src.device, dtype=torch.float32)
+        call("tvae_upsample_fwd", _p(src), src_rows, 0, _p(out), B, Lin, Cd, 1, 0, Lin, _stream())
+        ctx.save_for_backward(W0, W1, W2, *saved)
+        ctx.metas, ctx.B = metas, B
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        W = ctx.saved_tensors[:3]
+        saved = ctx.saved_tensors[3:]
+        B = ctx.B
+        grads = [None] * 6
+        # (dup, d_stride, d_lpad, d_Lup): where the gradient of layer li's OUTPUT rows lives
+        dup, d_stride, d_lpad, d_Lup = _c(dout), 1, 0, ctx.metas[2][1]
+        for li in (2, 1, 0):
+            Lin, Lout, Lup, Cin, Cout, k, s, lpad = ctx.metas[li]
+            up, y = saved[2 * li], saved[2 * li + 1]
+            buf = torch.zeros(((k - 1) + B * Lup, Cout), device=dup.device, dtype=torch.float32)
+            dyr = buf[k - 1:]
+            call("tvae_upsample_bwd", _p(dup), _p(y), _p(dyr), Lup, 0, B, Lout, Cout, d_stride, d_lpad, d_Lup,
+                 _stream())
+            dwp = _conv_wgrad(dyr, up, B * Lup, Cin, Cout, k)
+            grads[2 * li] = _unpack_dw(dwp, W[li].shape, Cout, Cin, k, True)
+            grads[2 * li + 1] = colsum(dyr)
+            if li > 0 or ctx.needs_input_grad[0]:
+                wd = _pack_w(W[li], Cin, Cout, k, False)                 # wd[ci][j*Cout+co] = W[ci][co][j]
+                dup = _conv_dgrad(buf, B * Lup, Cout, wd, Cin, k)        # gradient of the zero-stuffed input
+                d_stride, d_lpad, d_Lup = s, lpad, Lup
+        dh = None
+        if ctx.needs_input_grad[0]:
+            Lin, Lout, Lup, Cin, Cout, k, s, lpad = ctx.metas[0]
+            dh = torch.empty((B, Cin * Lin), device=dup.device, dtype=torch.float32)
+            call("tvae_upsample_bwd", _p(dup), None, _p(dh), Lin, 1, B, Lin, Cin, s, lpad, Lup, _stream())
+        return (dh,) + tuple(grads)
+
+
+# ----------------------------------------------------------------------------- loss
+def loss_fwd_bwd(tokens, logits, weights, pred_len, mu, logvar, pred_prop, true_prop, beta, pad_idx,
+                 want_grads=True, true_len=None):
+    """trans_vae_loss (reference loss.py:23-38) + its gradients in two launches.
+    Returns (out5 device tensor [total,bce,bce_mask,kld,mse], grads dict)."""
+    B, Lp1 = tokens.shape
+    L = Lp1 - 1
+    n_cls = logits.shape[-1]
+    lg = _c(logits).view(B * L, n_cls)
+    dev = lg.device
+    out5 = torch.empty(5, device=dev, dtype=torch.float32)
+    scratch = torch.empty(8, device=dev, dtype=torch.float32)
+    g = {}
+    if want_grads:
+        g["logits"] = torch.empty_like(lg)
+        g["pred_len"] = torch.empty_like(pred_len)
+        g["mu"] = torch.empty_like(mu)
+        g["logvar"] = torch.empty_like(logvar)
+        g["pred_prop"] = torch.empty(B, device=dev, dtype=torch.float32) if pred_prop is not None else None
+    pp = None if pred_prop is None else _c(pred_prop).view(-1)
+    tp = None if pred_prop is None else _c(true_prop.to(torch.float32)).view(-1)
+    tl = None if true_len is None else _c(true_len.long()).view(-1)
+    call("tvae_loss_fwd_bwd", _p(_c(tokens)), _p(lg), lg.stride(0), _p(weights), _p(_c(pred_len)), _p(_c(mu)),
+         _p(_c(logvar)), _p(pp), _p(tp), _p(tl), float(beta), B, L, n_cls, pred_len.shape[1], mu.shape[1], int(pad_idx),
+         _p(out5), _p(g.get("logits")), _p(g.get("pred_len")), _p(g.get("mu")), _p(g.get("logvar")),
+         _p(g.get("pred_prop")), _p(scratch), _stream())
+    return out5, g
+
+
+class LossFn(torch.autograd.Function):
+    """Autograd face of loss_fwd_bwd: returns the 5 scalars; backward scales the stored gradients
+    by the incoming gradient of `total` (the other four outputs are monitors)."""
+
+    @staticmethod
+    def forward(ctx, tokens, logits, mu, logvar, pred_len, true_prop, pred_prop, weights, beta, pad_idx, true_len):
+        out5, g = loss_fwd_bwd(tokens, logits, weights, pred_len, mu, logvar, pred_prop, true_prop, beta, pad_idx,
+                               true_len=true_len)
+        ctx.g = g
+        ctx.shapes = (logits.shape, None if pred_prop is None else pred_prop.shape)
+        total, bce, bmask, kld, mse = out5.unbind(0)
+        ctx.mark_non_differentiable(bce, bmask, kld, mse)
+        return total, bce, bmask, kld, mse
+
+    @staticmethod
+    def backward(ctx, gt, *_):
+        g = ctx.g
+        dpp = None
+        if g["pred_prop"] is not None:
+            dpp = (g["pred_prop"] * gt).view(ctx.shapes[1])
+        return (None, (g["logits"] * gt).view(ctx.shapes[0]), g["mu"] * gt, g["logvar"] * gt, g["pred_len"] * gt,
+                None, dpp, None, None, None, None)
+
+
+# ----------------------------------------------------------------------------- Adam
+class FusedAdam:
+    """One-launch Adam over a list of (param, grad, exp_avg, exp_avg_sq) tensors."""
+    CHUNK = 4096
+
+    def __init__(self, params, betas=(0.9, 0.98), eps=1e-9):
+        self.params = list(params)
+        dev = self.params[0].device
+        self.betas, self.eps = betas, eps
+        self.exp_avg = [torch.zeros_like(p) for p in self.params]
+        self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
+        self.hyper = torch.zeros(4, device=dev, dtype=torch.float32)
+        self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(4)
+        sizes = [p.numel() for p in self.params]
+        ct, cs = [], []
+        for i, n in enumerate(sizes):
+            for st in range(0, n, self.CHUNK):
+                ct.append(i)
+                cs.append(st)
+        self.n_chunks = len(ct)
+        self.sizes = torch.tensor(sizes, dtype=torch.int64, device=dev)
+        self.chunk_tensor = torch.tensor(ct, dtype=torch.int32, device=dev)
+        self.chunk_start = torch.tensor(cs, dtype=torch.int64, device=dev)
+        self._ptrs = None
+        self._ptr_key = None
+
+    def _ptr_table(self):
+        grads = []
+        for p in self.params:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            grads.append(p.grad)
+        key = tuple(t.data_ptr() for t in self.params + grads)
+        if key != self._ptr_key:
+            allp = [t.data_ptr() for t in self.params + grads + self.exp_avg + self.exp_avg_sq]
+            self._ptrs = torch.tensor(allp, dtype=torch.int64, device=self.params[0].device)
+            self._ptr_key = key
+        return self._ptrs
+
+    def set_hyper(self, lr, step, grad_scale=1.0):
+        b1, b2 = self.betas
+        self._hyper_host[0] = lr
+        self._hyper_host[1] = 1.0 - b1 ** step
+        self._hyper_host[2] = 1.0 - b2 ** step
+        self._hyper_host[3] = grad_scale
+        self.hyper.copy_(self._hyper_host, non_blocking=True)
+
+    def launch(self, zero_grad=False):
+        ptrs = self._ptr_table()
+        call("tvae_adam_multi", _p(ptrs), _p(self.sizes), _p(self.chunk_tensor), _p(self.chunk_start),
+             len(self.params), self.n_chunks, _p(self.hyper), self.betas[0], self.betas[1], self.eps,
+             int(zero_grad), _stream())
+
+
+class ResidualDropoutFn(torch.autograd.Function):
+    """out = res + dropout(x) (res optional): the generic SublayerConnection / nn.Dropout glue."""
+
+    @staticmethod
+    def forward(ctx, x, res, drop):
+        x2 = _c(x).view(-1, x.shape[-1])
+        out = torch.empty_like(x2)
+        r, s, p = _drop_args(drop)
+        res2 = None if res is None else _c(res).view(x2.shape)
+        call("tvae_residual_dropout", _p(x2), _p(res2), _p(out), x2.shape[0], x2.shape[1], 0, 0, r, s, p, _stream())
+        ctx.drop, ctx.has_res = drop, res is not None
+        return out.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy2 = _c(dy).view(-1, dy.shape[-1])
+        if ctx.drop is None:
+            dx = dy
+        else:
+            dx2 = torch.empty_like(dy2)
+            r, s, p = _drop_args(ctx.drop)
+            call("tvae_residual_dropout", _p(dy2), None, _p(dx2), dy2.shape[0], dy2.shape[1], 0, 0, r, s, p, _stream())
+            dx = dx2.view(dy.shape)
+        return dx, (dy if ctx.has_res else None), None
+
+
+class PosEncFn(torch.autograd.Function):
+    """out = dropout(x + pe[:L])  (PositionalEncoding.forward on its own, trans_models.py:1060-1063)."""
+
+    @staticmethod
+    def forward(ctx, x, pe, drop):
+        B, L, d = x.shape
+        x2 = _c(x).view(-1, d)
+        out = torch.empty_like(x2)
+        r, s, p = _drop_args(drop)
+        call("tvae_residual_dropout", _p(x2), _p(pe.view(-1, d)), _p(out), B * L, d, L, 1, r, s, p, _stream())
+        ctx.drop = drop
+        return out.view(B, L, d)
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.drop is None:
+            return dy, None, None
+        dy2 = _c(dy).view(-1, dy.shape[-1])
+        dx2 = torch.empty_like(dy2)
+        r, s, p = _drop_args(ctx.drop)
+        call("tvae_residual_dropout", _p(dy2), None, _p(dx2), dy2.shape[0], dy2.shape[1], 0, 0, r, s, p, _stream())
+        return dx2.view(dy.shape), None, None

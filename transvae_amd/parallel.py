@@ -1,0 +1,105 @@
+"""Data-parallel training: one process per GPU, gradients all-reduced over RCCL/xGMI.
+
+Layout: all parameter gradients live in ONE flat fp32 arena; ``p.grad`` of every parameter is a
+view into it, so autograd accumulates straight into the arena and no pack/unpack copy exists.
+The arena is cut into a few contiguous buckets in the order backward finishes them
+(generator + decoder layers -> deconv/linear -> encoder bottleneck -> encoder layers + embeddings).
+During the LAST accumulation chunk a bucket's all-reduce is launched (async, on RCCL's own
+stream) as soon as its last gradient has been accumulated, so communication overlaps the rest of
+backward; xGMI is point-to-point, so few large messages (3-4 buckets of ~8 MB for trans4x-256)
+is the shape that suits it.  The 1/world averaging is folded into the fused Adam launch
+(grad_scale), so no extra pass over the gradients is needed.
+
+Semantics: standard data parallelism -- every rank computes the reference's chunk-mean loss on its
+own molecules and gradients are averaged.  The weighted-mean CE normaliser differs per rank
+(SURVEY.md 8e), so this equals the single-GPU gradient on the concatenated batch only up to that
+normaliser (1e-4..1e-3 relative); documented in DESIGN.md.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradArena:
+    def __init__(self, model, n_buckets=4):
+        params = [p for p in model.parameters() if p.requires_grad]
+        # backward reaches parameters roughly in reverse registration order
+        order = list(reversed(params))
+        total = sum(p.numel() for p in order)
+        dev = order[0].device
+        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.buckets = []           # (start, end, set(param ids))
+        target = (total + n_buckets - 1) // n_buckets
+        off, bstart, members = 0, 0, []
+        self.bucket_of = {}
+        for p in order:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            members.append(p)
+            off += n
+            if off - bstart >= target or p is order[-1]:
+                bi = len(self.buckets)
+                for q in members:
+                    self.bucket_of[id(q)] = bi
+                self.buckets.append((bstart, off, len(members)))
+                bstart, members = off, []
+        self.params = order
+
+
+class DataParallel:
+    """Wraps a VAEShell: ``step(data, beta)`` = VAEShell.train_step with bucketed gradient all-reduce."""
+
+    def __init__(self, vae, n_buckets=4, overlap=True):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.vae = vae
+        self.world = dist.get_world_size()
+        self.arena = GradArena(vae.model, n_buckets)
+        self.overlap = overlap
+        self._armed = False
+        self._pending = []
+        self._count = [0] * len(self.arena.buckets)
+        if overlap:
+            for p in self.arena.params:
+                p.register_post_accumulate_grad_hook(self._hook)
+        # parameters start identical on every rank
+        for p in vae.model.parameters():
+            dist.broadcast(p.data, src=0)
+        self._set_grad_scale(1.0 / self.world)
+
+    def _set_grad_scale(self, s):
+        self.vae.optimizer.optimizer.grad_scale = s
+
+    def _hook(self, p):
+        if not self._armed:
+            return
+        bi = self.arena.bucket_of[id(p)]
+        self._count[bi] += 1
+        if self._count[bi] == self.arena.buckets[bi][2]:
+            self._launch(bi)
+
+    def _launch(self, bi):
+        s, e, _ = self.arena.buckets[bi]
+        self._pending.append(dist.all_reduce(self.arena.flat[s:e], op=dist.ReduceOp.SUM, async_op=True))
+
+    def arm(self):
+        "call before the backward of the last accumulation chunk"
+        self._armed = True
+        self._count = [0] * len(self.arena.buckets)
+        self._pending = []
+
+    def finish(self):
+        "after the last backward: reduce whatever was not launched from hooks, wait for all buckets"
+        if not self.overlap or not self._armed:
+            for bi in range(len(self.arena.buckets)):
+                self._launch(bi)
+        else:
+            for bi, c in enumerate(self._count):
+                if c != self.arena.buckets[bi][2]:        # a parameter got no gradient this step
+                    self._launch(bi)
+        for w in self._pending:
+            w.wait()
+        self._armed = False
+        self._pending = []
+
+    def step(self, data, beta, eps=None):
+        return self.vae.train_step(data, beta, eps=eps, dp=self)

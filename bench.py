@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Benchmark of the TransVAE hot path on MI355X: trans4x-256 training step (forward + loss +
+backward + Noam/Adam, dropout ON as the reference trains) and KV-cached greedy decode.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3            # one GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  `value` = whole-job train tokens/s (B*126 target positions per
+step and rank, pads included: the algorithm is dense), inputs resident in HBM.
+Extra keys: decode molecules/s, `roofline` for the dominant kernel (the MFMA GEMM, timed live
+with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle -- a port of the
+reference's path pinned by golden vectors -- timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}     # MI355X_MICROARCH.md: dense MFMA peaks
+FLOP_PER_MOL_FWD_BWD = 5.940e9                      # trans4x-256, SURVEY.md 8(d)
+FLOP_PER_MOL_DECODE = 1.196e9
+
+
+def build_vae(arch="trans4x-256", batch=500, chunks=5):
+    from transvae_amd import synth
+    from transvae_amd.trans_models import TransVAE
+    cd, od, w = synth.load_vocab("zinc")
+    params = {"CHAR_DICT": cd, "ORG_DICT": od, "CHAR_WEIGHTS": w, "BATCH_SIZE": batch, "BATCH_CHUNKS": chunks}
+    vae = TransVAE(params=params, name="bench", **synth.ARCHS[arch])
+    vae.model.load_state_dict(synth.synth_state_dict(vae.model.state_dict(), 0))
+    return vae
+
+
+def time_gemm(M, N, K, dtype_name, iters=20):
+    """Average duration (s) of the dominant kernel on one representative launch shape."""
+    from transvae_amd import ops
+    x = torch.randn(M, K, device="cuda")
+    w = torch.randn(N, K, device="cuda") * 0.05
+    b = torch.zeros(N, device="cuda")
+    out = torch.empty(M, N, device="cuda")
+    for _ in range(3):
+        ops.linear_fwd(x, w, b, relu=True, out=out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()                     # events on torch's current stream == the launch stream
+    for _ in range(iters):
+        ops.linear_fwd(x, w, b, relu=True, out=out)
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def cpu_baseline(threads, n_mols=100, timed=2):
+    """The oracle's chunk (fwd + loss + bwd, dropout on like scripts/train.py) on host cores."""
+    import numpy as np
+    from oracle import tvae_oracle as O
+    from transvae_amd import synth
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import oracle_params
+    torch.set_num_threads(threads)
+    P = oracle_params("4x256_zinc", torch.float32, requires_grad=True)
+    w = torch.tensor(synth.load_vocab("zinc")[2], dtype=torch.float32)
+    toks = synth.synth_tokens(n_mols, seed=1)
+    times = []
+    for it in range(timed + 1):
+        for v in P.values():
+            v.grad = None
+        t0 = time.perf_counter()
+        losses, _ = O.chunk_loss(P, toks, torch.zeros(n_mols), w, 0.01, p_drop=0.1, attn_drop=0.1)
+        losses[0].backward()
+        times.append(time.perf_counter() - t0)
+    t = float(np.mean(times[1:]))
+    return {"value": n_mols * 126 / t, "unit": "tokens/s", "cores": threads, "kind": "port",
+            "sample": "%d chunk(s) of %d molecules, trans4x-256 fwd+loss+bwd, dropout 0.1, fp32 torch CPU oracle "
+                      "(1 warm-up + %d timed, %.2f s each)" % (timed, n_mols, timed, t)}
+
+
+def cpu_decode_baseline(threads, n=4):
+    from oracle import tvae_oracle as O
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import oracle_params
+    torch.set_num_threads(threads)
+    P = oracle_params("4x256_zinc", torch.float32)
+    z = torch.randn(n, 128, generator=torch.Generator().manual_seed(0))
+    t0 = time.perf_counter()
+    O.greedy_decode(P, z)
+    t = time.perf_counter() - t0
+    return {"value": n / t, "unit": "molecules/s", "cores": threads, "kind": "port",
+            "sample": "%d latents, reference-style full-recompute greedy loop, %.1f s" % (n, t)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32")
+    ap.add_argument("--batch", type=int, default=500)
+    ap.add_argument("--chunks", type=int, default=5)
+    ap.add_argument("--decode-n", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl")
+    dev = torch.device("cuda", local)
+
+    from transvae_amd import ops, synth
+    ops.set_compute_dtype(args.dtype)
+    vae = build_vae(batch=args.batch, chunks=args.chunks)
+    vae.model.train()                                   # dropout on: what scripts/train.py runs
+    ops.seed_rng(dev, 1234 + rank)
+    dp = None
+    if world > 1:
+        from transvae_amd.parallel import DataParallel
+        dp = DataParallel(vae)
+    toks = synth.synth_tokens(args.batch, seed=100 + rank).float()
+    data = torch.cat([toks, torch.zeros(args.batch, 1)], 1).to(dev)     # resident in HBM
+    beta = 0.01
+
+    def step():
+        return vae.train_step(data, beta, dp=dp)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        table = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    last_loss = float(table[:, 0].mean().item())
+    tokens = world * args.batch * 126 * args.steps
+    value = tokens / dt
+
+    out = {
+        "metric": "train tokens/s (fwd+bwd) + decoded mols/s, trans4x-256, 1/2/4/8 MI355X",
+        "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
+        "config": {"workload": "trans4x-256 ZINC-vocab train step (fwd+loss+bwd+Noam/Adam), batch %d = %d chunks x %d "
+                               "per GPU, max_len 126, dropout 0.1, synthetic SMILES-shaped tokens, synthetic checkpoint"
+                               % (args.batch, args.chunks, args.batch // args.chunks),
+                   "global_batch": world * args.batch, "seq_len": 126,
+                   "parallelism": "dp%d" % world if world > 1 else "single"},
+        "final_loss": last_loss,
+        "train_algorithmic_tflops": world * args.batch * FLOP_PER_MOL_FWD_BWD * args.steps / dt / 1e12,
+        "train_frac_of_mfma_peak": (args.batch * FLOP_PER_MOL_FWD_BWD * args.steps / dt / 1e12) / PEAK_TFLOPS[args.dtype],
+    }
+
+    # ---- greedy decode (KV-cached), sharded by latent batch: every rank decodes its own slab ------
+    if not args.no_decode:
+        vae.model.eval()
+        z = torch.randn(args.decode_n, 128, generator=torch.Generator().manual_seed(rank)).to(dev)
+        vae.greedy_decode(z[:64])
+        fence()
+        t0 = time.perf_counter()
+        ids = vae.greedy_decode(z)
+        fence()
+        td = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([td], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            td = float(tmax.item())
+            gathered = [torch.empty_like(ids, dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
+            dist.gather(ids.to(torch.uint8), gathered, dst=0)          # the one exchange: final token ids
+        out["decode_mols_per_s"] = world * args.decode_n / td
+        out["decode_batch_per_gpu"] = args.decode_n
+        out["decode_algorithmic_tflops"] = world * args.decode_n * FLOP_PER_MOL_DECODE / td / 1e12
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: the MFMA GEMM on the FFN w_1 launch shape -----------
+        M, N, K = (args.batch // args.chunks) * 127, 1024, 256
+        tg = time_gemm(M, N, K, args.dtype)
+        flops = 2.0 * M * N * K
+        ach = flops / tg / 1e12
+        out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                           "frac": ach / PEAK_TFLOPS[args.dtype], "traffic": None,
+                           "kernel": "gemm_kernel (x[%d,%d] @ W[%d,%d]^T + bias, ReLU)" % (M, K, N, K),
+                           "launch_us": tg * 1e6, "flop_per_launch": flops}
+        if not args.no_cpu_baseline and world == 1:
+            threads = min(16, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(threads)
+            out["cpu_baseline_decode"] = cpu_decode_baseline(threads)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

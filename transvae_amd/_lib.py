@@ -6,6 +6,10 @@ There is NO fallback: if the library is missing or does not load, importing this
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- FIRST: torch bundles its own libamdhip64; loading ours before it would
+#                              put two HIP runtimes in the process (kernels launched on a stream of
+#                              the other runtime fail with "no ROCm-capable device is detected")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtvae_hip.so")
 

@@ -61,11 +61,13 @@ const char* tvae_version(void);
  * data- and weight-gradient products, and, via overlapping rows (lda < K), the Conv1d /
  * ConvTranspose1d contractions of ConvBottleneck / DeconvBottleneck (:980-983, :1006-1009).
  * Unaligned operands (ld or K not a multiple of 4) take a scalar-load path.
+ * a_rowsum (k-major A only, else NULL): a_rowsum[m] += sum_k A(m,k) with the A dropout scale applied --
+ * the bias gradient sum_rows dY, produced by the weight-gradient launch that reads dY anyway.
  */
 int tvae_gemm(const float* A, int lda, const float* B, int ldb, float* C, int ldc,
               int M, int N, int K, const float* bias, const float* residual, int ldr,
               float alpha, int flags, const uint32_t* rng, uint32_t site, float p_drop,
-              int dtype, void* stream);
+              float* a_rowsum, int dtype, void* stream);
 
 /* out[n] (+)= sum_m X[m*ld + n] (* dropout keep-scale if rng): bias gradients. */
 int tvae_colsum(const float* X, int ld, float* out, int M, int N, int accumulate,
@@ -173,16 +175,18 @@ int tvae_reparam_bwd(const float* dz, const float* logvar, const float* eps, flo
  *   is what the reference passes (src_mask.sum(-1), trans_models.py:219)
  *   logits (B*126, ldl >= 25) ; weights (25) ; pred_len (B,128) ; mu/logvar (B,dl)
  *   pred_prop (B) / true_prop (B) or NULL
- *   out[5] = {total, bce_mol, bce_mask, kld, mse} (written, not accumulated)
+ *   n_groups: the batch is n_groups consecutive chunks, each normalised on its own exactly like one
+ *   chunk of VAEShell.train (trans_models.py:202-236); gradients are those of the SUM of the chunk losses
+ *   out5 (n_groups, 5) = {total, bce_mol, bce_mask, kld, mse} per chunk (written, not accumulated)
  *   dlogits (B*126, ldl), dpred_len, dmu, dlogvar, dpred_prop: gradients of `total`
- *   scratch: >= 8 floats of device workspace (zeroed by the call)
+ *   scratch: >= 8*n_groups floats of device workspace (zeroed by the call)
  * KLD NaN guard (loss.py:36-37): if the KLD term is NaN it contributes 0 and no gradient.
  */
 int tvae_loss_fwd_bwd(const int64_t* tokens, const float* logits, int ldl, const float* weights,
                       const float* pred_len, const float* mu, const float* logvar,
                       const float* pred_prop, const float* true_prop, const int64_t* true_len,
                       float beta,
-                      int B, int L, int n_cls, int n_len, int d_latent, int pad_idx,
+                      int B, int L, int n_cls, int n_len, int d_latent, int pad_idx, int n_groups,
                       float* out5, float* dlogits, float* dpred_len, float* dmu, float* dlogvar,
                       float* dpred_prop, float* scratch, void* stream);
 

@@ -246,3 +246,25 @@ def test_generic_module_paths_agree_with_fused_paths():
         y = layer.sublayer[0](x, lambda t: layer.self_attn(t, t, t, mask))
         y = layer.sublayer[1](y, layer.feed_forward)
     assert rel_l2(y.cpu(), fused.cpu()) < 1e-6
+
+
+def test_fused_chunks_equal_literal_chunk_loop():
+    """One pass over the batch with per-chunk loss normalisation == the reference's chunk loop:
+    same per-chunk losses, same accumulated gradients (dropout off, same eps)."""
+    from transvae_amd import synth
+    grads, tables = [], []
+    toks = synth.synth_tokens(24, seed=9).float()
+    data = torch.cat([toks, torch.zeros(24, 1)], 1)
+    eps = torch.randn(24, 128, generator=torch.Generator().manual_seed(4)).cuda()
+    for fuse in (True, False):
+        vae = build("1x128_zinc", BATCH_SIZE=24, BATCH_CHUNKS=3, FUSE_CHUNKS=fuse)
+        vae.model.eval()
+        vae.optimizer.optimizer.fuse_zero_grad = False       # keep the gradients to look at them
+        tables.append(vae.train_step(data, 0.03, eps=eps).cpu().numpy())
+        grads.append({k: p.grad.detach().cpu().numpy().copy() for k, p in vae.model.named_parameters()})
+    np.testing.assert_allclose(tables[0], tables[1], rtol=2e-6, atol=1e-7)
+    for k in grads[0]:
+        if k.endswith("attn.linears.1.bias"):       # analytically zero (softmax shift invariance): noise only
+            assert np.linalg.norm(grads[0][k]) < 1e-5 and np.linalg.norm(grads[1][k]) < 1e-5
+        else:
+            assert rel_l2(grads[0][k], grads[1][k]) < 2e-5, k

@@ -1,0 +1,109 @@
+"""Data-parallel gradient arena + bucketed all-reduce on CPU (gloo, world_size 2).  The HIP model
+cannot run here, so a small torch model stands in for it: what is under test is the arena layout,
+the bucket bookkeeping (hook route and direct-accumulation 'sink' route) and the reduction."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _Opt:
+    def __init__(self):
+        self.optimizer = type("O", (), {"grad_scale": 1.0})()
+
+
+class _Shell:
+    def __init__(self, model):
+        self.model = model
+        self.optimizer = _Opt()
+
+
+def _model():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(), torch.nn.Linear(32, 32), torch.nn.Tanh(),
+                               torch.nn.Linear(32, 4))
+
+
+def _worker(rank, world, port, overlap, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from transvae_amd.parallel import DataParallel
+    torch.manual_seed(100 + rank)
+    model = _model()
+    if rank == 1:                      # ranks start different: the constructor must broadcast rank 0's weights
+        for p in model.parameters():
+            p.data.add_(1.0)
+    dp = DataParallel(_Shell(model), n_buckets=3, overlap=overlap)
+    g = torch.Generator().manual_seed(5)
+    x, y = torch.randn(8, 16, generator=g), torch.randn(8, 4, generator=g)
+    xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+    for step in range(2):              # two steps: the arena must be reusable after zeroing
+        dp.arena.flat.zero_()
+        # chunk 1 (not armed), chunk 2 (armed): accumulate like VAEShell.train_step
+        ((model(xs[:2]) - ys[:2]) ** 2).mean().backward()
+        dp.arm()
+        ((model(xs[2:]) - ys[2:]) ** 2).mean().backward()
+        dp.finish()
+    scale = dp.vae.optimizer.optimizer.grad_scale
+    q.put((rank, (dp.arena.flat * scale).clone(), [p.grad.data_ptr() for p in model.parameters()],
+           dp.arena.flat.data_ptr(), len(dp.arena.buckets)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(overlap):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process truth: average over ranks of (sum over the rank's two chunk-mean gradients)
+    model = _model()
+    g = torch.Generator().manual_seed(5)
+    x, y = torch.randn(8, 16, generator=g), torch.randn(8, 4, generator=g)
+    for r in range(2):
+        xs, ys = x[r * 4:(r + 1) * 4], y[r * 4:(r + 1) * 4]
+        ((model(xs[:2]) - ys[:2]) ** 2).mean().backward()
+        ((model(xs[2:]) - ys[2:]) ** 2).mean().backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in reversed(list(model.parameters()))]) / 2
+    for rank, flat, ptrs, base, nb in res:
+        assert 2 <= nb <= 3
+        assert torch.allclose(flat, ref, rtol=1e-5, atol=1e-7), (rank, (flat - ref).abs().max())
+        assert all(base <= p < base + flat.numel() * 4 for p in ptrs)       # every grad is an arena view
+    assert torch.equal(res[0][1], res[1][1])
+
+
+def test_bucketed_allreduce_overlapped_hooks():
+    _run(True)
+
+
+def test_bucketed_allreduce_no_overlap():
+    _run(False)
+
+
+def test_grad_sink_counts_multi_use_parameters():
+    from transvae_amd import ops
+    done = []
+    sink = ops.GradSink(on_complete=lambda p: done.append(p.data_ptr()))
+    a, b = torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(2))
+    sink.use(a); sink.use(a); sink.use(b)
+    sink.done(a)
+    assert done == []
+    sink.done(b); sink.done(a)
+    assert done == [b.data_ptr(), a.data_ptr()]
+    assert sink.target(a) is a.grad and a.grad.shape == a.shape

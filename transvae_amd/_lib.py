@@ -20,7 +20,7 @@ _vp, _i, _f, _u = C.c_void_p, C.c_int, C.c_float, C.c_uint32
 
 # name -> argtypes; every function returns int (0 = ok) except the two string getters.
 SIGNATURES = {
-    "tvae_gemm": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _f, _i, _vp, _u, _f, _i, _vp],
+    "tvae_gemm": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _f, _i, _vp, _u, _f, _vp, _i, _vp],
     "tvae_colsum": [_vp, _i, _vp, _i, _i, _i, _vp, _u, _f, _vp],
     "tvae_layernorm_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "tvae_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
@@ -37,7 +37,7 @@ SIGNATURES = {
     "tvae_upsample_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "tvae_reparam_fwd": [_vp, _vp, _vp, _vp, _i, _f, _vp],
     "tvae_reparam_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _f, _vp],
-    "tvae_loss_fwd_bwd": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i,
+    "tvae_loss_fwd_bwd": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i, _i,
                           _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "tvae_adam_multi": [_vp, _vp, _vp, _vp, _i, _i, _vp, _f, _f, _f, _i, _vp],
     "tvae_decode_attn": [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp],

@@ -30,6 +30,7 @@ struct GemmArgs {
   float alpha; int flags;
   const uint32_t* rng; uint32_t site; float p;
   int k_per_split;
+  float* a_rowsum;   // A_KMAJOR only: a_rowsum[m] += sum_k A(m,k) (bias gradient fused into wgrad)
 };
 
 __device__ inline unsigned short f2bf(float f) {
@@ -136,6 +137,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
   float4 sa[4], sb[4];
   DropCfg nodrop = drop_cfg(nullptr, 0, 0.f);
+  // fused bias gradient: in k-major staging all four float4 of a thread cover the same 4 rows
+  const bool do_rowsum = A_KM && (g.a_rowsum != nullptr) && (tile_n == 0);
+  float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto add_rowsum = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { rs.x += sa[j].x; rs.y += sa[j].y; rs.z += sa[j].z; rs.w += sa[j].w; }
+  };
 
   auto tileA = [&](int buf) { return lds + (buf * 2 + 0) * TILE_FLOATS; };
   auto tileB = [&](int buf) { return lds + (buf * 2 + 1) * TILE_FLOATS; };
@@ -143,6 +151,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   if (nkt > 0) {
     stage_load<A_KM, ALIGNED, DROP>(sa, g.A, g.lda, m0, g.M, kbeg, kend, tid, dc, g.M, g.K);
     stage_load<B_KM, ALIGNED, false>(sb, g.B, g.ldb, n0, g.N, kbeg, kend, tid, nodrop, 0, 0);
+    if (do_rowsum) add_rowsum();
     if (BF16) {
       stage_store_bf16<A_KM>(sa, reinterpret_cast<unsigned short*>(tileA(0)), tid);
       stage_store_bf16<B_KM>(sb, reinterpret_cast<unsigned short*>(tileB(0)), tid);
@@ -223,6 +232,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], b[j][ks], acc[i][j], 0, 0, 0);
     }
     if (more) {
+      if (do_rowsum) add_rowsum();     // after the MFMAs: the loads have landed by now
       if (BF16) {
         stage_store_bf16<A_KM>(sa, reinterpret_cast<unsigned short*>(tileA(buf ^ 1)), tid);
         stage_store_bf16<B_KM>(sb, reinterpret_cast<unsigned short*>(tileB(buf ^ 1)), tid);
@@ -232,6 +242,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       }
     }
     __syncthreads();
+  }
+
+  if (do_rowsum) {   // every thread is past the last barrier of the k-loop: LDS is free
+    float* red = lds;
+    *reinterpret_cast<float4*>(&red[(tid >> 5) * BM + (tid & 31) * 4]) = rs;
+    __syncthreads();
+    if (tid < BM && m0 + tid < g.M) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += red[w * BM + tid];
+      atomicAdd(&g.a_rowsum[m0 + tid], t);
+    }
   }
 
   // ---- epilogue ----------------------------------------------------------------------------
@@ -290,7 +312,7 @@ void launch1(const GemmArgs& g, dim3 grid, hipStream_t s, bool aligned, bool bf1
 extern "C" int tvae_gemm(const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                          int M, int N, int K, const float* bias, const float* residual, int ldr,
                          float alpha, int flags, const uint32_t* rng, uint32_t site, float p_drop,
-                         int dtype, void* stream) {
+                         float* a_rowsum, int dtype, void* stream) {
   TVAE_CHECK(A && B && C, TVAE_E_NULL, "tvae_gemm: null operand");
   TVAE_CHECK(M > 0 && N > 0 && K > 0, TVAE_E_SHAPE, "tvae_gemm: M,N,K must be positive (%d,%d,%d)", M, N, K);
   TVAE_CHECK(dtype == TVAE_F32 || dtype == TVAE_BF16, TVAE_E_DTYPE, "tvae_gemm: dtype %d", dtype);
@@ -315,6 +337,8 @@ extern "C" int tvae_gemm(const float* A, int lda, const float* B, int ldb, float
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.res = residual;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.M = M; g.N = N; g.K = K;
   g.alpha = alpha; g.flags = flags; g.rng = rng; g.site = site; g.p = p_drop;
+  g.a_rowsum = a_rowsum;
+  TVAE_CHECK(!a_rowsum || a_km, TVAE_E_SHAPE, "tvae_gemm: a_rowsum needs a k-major A (wgrad form)");
   int tiles = cdiv(M, BM) * cdiv(N, BN);
   int splits = 1;
   if (flags & TVAE_GEMM_SPLITK) {

@@ -18,12 +18,37 @@ __device__ inline float block_sum(float v, float* red) {
 struct LossArgs {
   const int64_t* tokens; const float* logits; int ldl; const float* weights; const float* pred_len;
   const float* mu; const float* logvar; const float* pred_prop; const float* true_prop; const int64_t* true_len; float beta;
-  int B, L, n_cls, n_len, d_latent, pad_idx;
+  int B, L, n_cls, n_len, d_latent, pad_idx, n_groups;
   float *out5, *dlogits, *dpred_len, *dmu, *dlogvar, *dpred_prop, *scratch;
 };
 
+
+// The reference accumulates the gradients of BATCH_CHUNKS separately-normalised chunk losses
+// (trans_models.py:202-236).  One launch handles all chunks: blockIdx.y selects the chunk
+// ("group"), every pointer is shifted to that chunk's molecules and B becomes the chunk size.
+__device__ inline LossArgs for_group(LossArgs a, int g) {
+  const int Bg = a.B / a.n_groups;
+  const size_t m0 = (size_t)g * Bg;
+  a.tokens += m0 * (a.L + 1);
+  a.logits += m0 * a.L * a.ldl;
+  a.pred_len += m0 * a.n_len;
+  a.mu += m0 * a.d_latent;
+  a.logvar += m0 * a.d_latent;
+  if (a.pred_prop) { a.pred_prop += m0; a.true_prop += m0; }
+  if (a.true_len) a.true_len += m0;
+  a.out5 += 5 * g;
+  a.scratch += 8 * g;
+  if (a.dlogits) a.dlogits += m0 * a.L * a.ldl;
+  if (a.dpred_len) a.dpred_len += m0 * a.n_len;
+  if (a.dmu) { a.dmu += m0 * a.d_latent; a.dlogvar += m0 * a.d_latent; }
+  if (a.dpred_prop) a.dpred_prop += m0;
+  a.B = Bg;
+  return a;
+}
+
 // scratch: [0] sum w[y]  [1] sum w[y]*nll  [2] sum nll_len  [3] sum (1+lv-mu^2-e^lv)  [4] sum (pp-tp)^2
-__global__ __launch_bounds__(256) void loss_reduce_kernel(LossArgs a) {
+__global__ __launch_bounds__(256) void loss_reduce_kernel(LossArgs a0) {
+  const LossArgs a = for_group(a0, blockIdx.y);
   __shared__ float red[4];
   const int tid = threadIdx.x, lane = tid & 63;
   float den = 0.f, num = 0.f;
@@ -89,7 +114,8 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(LossArgs a) {
   }
 }
 
-__global__ __launch_bounds__(256) void loss_grad_kernel(LossArgs a) {
+__global__ __launch_bounds__(256) void loss_grad_kernel(LossArgs a0) {
+  const LossArgs a = for_group(a0, blockIdx.y);
   const int tid = threadIdx.x, lane = tid & 63;
   const float den = a.scratch[0];
   const float bce = a.scratch[1] / den;
@@ -277,7 +303,7 @@ inline int grid_for(size_t total) {
 extern "C" int tvae_loss_fwd_bwd(const int64_t* tokens, const float* logits, int ldl, const float* weights,
                                  const float* pred_len, const float* mu, const float* logvar, const float* pred_prop,
                                  const float* true_prop, const int64_t* true_len, float beta, int B, int L, int n_cls, int n_len, int d_latent,
-                                 int pad_idx, float* out5, float* dlogits, float* dpred_len, float* dmu, float* dlogvar,
+                                 int pad_idx, int n_groups, float* out5, float* dlogits, float* dpred_len, float* dmu, float* dlogvar,
                                  float* dpred_prop, float* scratch, void* stream) {
   TVAE_CHECK(tokens && logits && weights && pred_len && mu && logvar && out5 && scratch, TVAE_E_NULL,
              "tvae_loss_fwd_bwd: null pointer");
@@ -286,13 +312,14 @@ extern "C" int tvae_loss_fwd_bwd(const int64_t* tokens, const float* logits, int
   TVAE_CHECK(!pred_prop || true_prop, TVAE_E_NULL, "tvae_loss_fwd_bwd: pred_prop without true_prop");
   TVAE_CHECK((dmu == nullptr) == (dlogvar == nullptr), TVAE_E_NULL, "tvae_loss_fwd_bwd: dmu/dlogvar must come together");
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(scratch, 0, 8 * sizeof(float), s) != hipSuccess) {
+  TVAE_CHECK(n_groups >= 1 && B % n_groups == 0, TVAE_E_SHAPE, "tvae_loss_fwd_bwd: B=%d not divisible into %d groups", B, n_groups);
+  if (hipMemsetAsync(scratch, 0, 8 * n_groups * sizeof(float), s) != hipSuccess) {
     tvae_set_error("tvae_loss_fwd_bwd: memset failed");
     return TVAE_E_LAUNCH;
   }
   LossArgs a = {tokens, logits, ldl, weights, pred_len, mu, logvar, pred_prop, true_prop, true_len, beta,
-                B, L, n_cls, n_len, d_latent, pad_idx, out5, dlogits, dpred_len, dmu, dlogvar, dpred_prop, scratch};
-  dim3 grid(cdiv((long)B * L, 256));
+                B, L, n_cls, n_len, d_latent, pad_idx, n_groups, out5, dlogits, dpred_len, dmu, dlogvar, dpred_prop, scratch};
+  dim3 grid(cdiv((long)(B / n_groups) * L, 256), n_groups);
   hipLaunchKernelGGL(loss_reduce_kernel, grid, dim3(256), 0, s, a);
   hipLaunchKernelGGL(loss_grad_kernel, grid, dim3(256), 0, s, a);
   TVAE_LAUNCH_CHECK("tvae_loss_fwd_bwd");

@@ -5,6 +5,40 @@
 
 namespace {
 
+// contiguous per-lane run of NPL floats, moved with the widest aligned vector the run allows
+template <int NPL>
+__device__ inline void load_run(float (&v)[NPL], const float* __restrict__ p) {
+  if constexpr (NPL % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < NPL; i += 4) {
+      float4 t = *reinterpret_cast<const float4*>(p + i);
+      v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
+    }
+  } else if constexpr (NPL % 2 == 0) {
+#pragma unroll
+    for (int i = 0; i < NPL; i += 2) {
+      float2 t = *reinterpret_cast<const float2*>(p + i);
+      v[i] = t.x; v[i + 1] = t.y;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) v[i] = p[i];
+  }
+}
+template <int NPL>
+__device__ inline void store_run(float* __restrict__ p, const float (&v)[NPL]) {
+  if constexpr (NPL % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < NPL; i += 4) *reinterpret_cast<float4*>(p + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+  } else if constexpr (NPL % 2 == 0) {
+#pragma unroll
+    for (int i = 0; i < NPL; i += 2) *reinterpret_cast<float2*>(p + i) = make_float2(v[i], v[i + 1]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) p[i] = v[i];
+  }
+}
+
 // ---------------------------------------------------------------------------- LayerNorm
 // Reference semantics (transvae/trans_models.py:1084-1087): mean over the last dim, UNBIASED
 // std (divisor d-1), eps added to std:  y = a * (x - mean) / (std + eps) + b.
@@ -16,10 +50,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   constexpr int d = 64 * NPL;
-  const float* xr = x + (size_t)row * d + lane * NPL;
-  float v[NPL];
-#pragma unroll
-  for (int i = 0; i < NPL; ++i) v[i] = xr[i];
+  float v[NPL], av[NPL], bv[NPL];
+  load_run<NPL>(v, x + (size_t)row * d + lane * NPL);
+  load_run<NPL>(av, a + lane * NPL);
+  load_run<NPL>(bv, b + lane * NPL);
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NPL; ++i) s += v[i];
@@ -29,9 +63,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   for (int i = 0; i < NPL; ++i) { v[i] -= mean; ss += v[i] * v[i]; }
   const float sd = sqrtf(wave_sum(ss) * (1.f / (d - 1)));
   const float rinv = 1.f / (sd + eps);
-  float* yr = y + (size_t)row * d + lane * NPL;
 #pragma unroll
-  for (int i = 0; i < NPL; ++i) yr[i] = a[lane * NPL + i] * v[i] * rinv + b[lane * NPL + i];
+  for (int i = 0; i < NPL; ++i) v[i] = av[i] * v[i] * rinv + bv[i];
+  store_run<NPL>(y + (size_t)row * d + lane * NPL, v);
 }
 
 // dx_i = r*(g_i - mean(g)) - xc_i * r^2 * sum_j(g_j xc_j) / ((d-1) sd),  g = dy*a, r = 1/(sd+eps)
@@ -46,15 +80,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
   __shared__ float red[2][4][d];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float av[NPL], pa[NPL], pb[NPL];
+  load_run<NPL>(av, a + lane * NPL);
 #pragma unroll
-  for (int i = 0; i < NPL; ++i) { av[i] = a[lane * NPL + i]; pa[i] = 0.f; pb[i] = 0.f; }
+  for (int i = 0; i < NPL; ++i) { pa[i] = 0.f; pb[i] = 0.f; }
   const int rbeg = blockIdx.x * rows_per_wg;
   const int rend = min(rows, rbeg + rows_per_wg);
   for (int row = rbeg + wave; row < rend; row += 4) {
     const size_t off = (size_t)row * d + lane * NPL;
-    float v[NPL], g[NPL];
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) { v[i] = x[off + i]; g[i] = dy[off + i]; }
+    float v[NPL], g[NPL], res[NPL];
+    load_run<NPL>(v, x + off);
+    load_run<NPL>(g, dy + off);
+    if (add_to) load_run<NPL>(res, add_to + off);
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NPL; ++i) s += v[i];
@@ -79,9 +115,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
       float o = rinv * (g[i] - sg) - v[i] * c2;
-      if (add_to) o += add_to[off + i];
-      dx[off + i] = o;
+      if (add_to) o += res[i];
+      g[i] = o;
     }
+    store_run<NPL>(dx + off, g);
   }
 #pragma unroll
   for (int i = 0; i < NPL; ++i) { red[0][wave][lane * NPL + i] = pa[i]; red[1][wave][lane * NPL + i] = pb[i]; }
@@ -336,7 +373,8 @@ extern "C" int tvae_layernorm_bwd(const float* x, const float* a, const float* d
   TVAE_CHECK(rows > 0 && d % 64 == 0 && d >= 64 && d <= 512, TVAE_E_SHAPE,
              "tvae_layernorm_bwd: d=%d must be a multiple of 64 in [64,512], rows=%d", d, rows);
   hipStream_t s = (hipStream_t)stream;
-  int rpw = 64;
+  int rpw = rows / 2048;          // aim at ~2048 workgroups; 4 waves walk rpw rows
+  rpw = rpw < 8 ? 8 : (rpw > 64 ? 64 : (rpw + 3) / 4 * 4);
   dim3 grid(cdiv(rows, rpw));
   switch (d / 64) {
     LN_DISPATCH(1, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)

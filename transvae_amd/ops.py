@@ -93,10 +93,69 @@ def _chk(t, name):
 
 # ----------------------------------------------------------------------------- raw launchers
 def gemm(A, lda, Bm, ldb, Cm, ldc, M, N, K, bias=None, residual=None, ldr=0, alpha=1.0, flags=0,
-         drop=None, dtype=None):
+         drop=None, dtype=None, a_rowsum=None):
     r, s, p = _drop_args(drop)
     call("tvae_gemm", _p(A), lda, _p(Bm), ldb, _p(Cm), ldc, M, N, K, _p(bias), _p(residual), ldr,
-         alpha, flags, r, s, p, _state["dtype"] if dtype is None else dtype, _stream())
+         alpha, flags, r, s, p, _p(a_rowsum), _state["dtype"] if dtype is None else dtype, _stream())
+
+
+# ---- direct gradient accumulation -------------------------------------------------------------
+# Inside VAEShell.train_step the weight/bias/LayerNorm/embedding gradients are accumulated by the
+# kernels STRAIGHT into param.grad (split-K atomics and column sums add into it anyway) and the
+# Functions return None for those inputs: no zero-filled temporaries, no AccumulateGrad add per
+# parameter and chunk.  Outside of it (plain loss.backward() on the modules) gradients are returned
+# to autograd as usual.
+class GradSink:
+    """Hands out param.grad buffers; `uses`/`done` let data parallelism know when a parameter's
+    gradient is complete (a parameter can be used more than once per step: decoder.norm)."""
+
+    def __init__(self, on_complete=None):
+        self.pending = {}
+        self.on_complete = on_complete
+
+    def use(self, p):
+        self.pending[p.data_ptr()] = self.pending.get(p.data_ptr(), 0) + 1
+
+    def target(self, p):
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        return p.grad
+
+    def done(self, p):
+        n = self.pending.get(p.data_ptr(), 0) - 1
+        self.pending[p.data_ptr()] = n
+        if n <= 0 and self.on_complete is not None:
+            self.on_complete(p)
+
+
+_sink = [None]
+
+
+class direct_grads:
+    def __init__(self, sink):
+        self.sink = sink
+
+    def __enter__(self):
+        self.prev = _sink[0]
+        _sink[0] = self.sink
+        return self.sink
+
+    def __exit__(self, *exc):
+        _sink[0] = self.prev
+
+
+def _direct(*params):
+    """True if every given parameter can take its gradient directly (leaf, requires grad, sink on)."""
+    if _sink[0] is None:
+        return False
+    return all(p is not None and p.is_leaf and p.requires_grad and p.is_contiguous() for p in params)
+
+
+def _note_use(*params):
+    if _sink[0] is not None:
+        for p in params:
+            if p is not None and p.is_leaf and p.requires_grad:
+                _sink[0].use(p)
 
 
 def linear_fwd(x, W, b=None, relu=False, residual=None, drop=None, out=None):
@@ -126,14 +185,26 @@ def linear_dgrad(dy, W, out=None, accumulate=False, relumask=None, alpha=1.0, a_
     return out
 
 
-def linear_wgrad(dy, x, a_drop=None, want_bias=True):
-    """dW[N,K] = (dy*keepscale)^T x (split-K, fp32 atomics into zeros), db[N] = colsum."""
+def linear_wgrad(dy, x, a_drop=None, want_bias=True, W=None, b=None):
+    """dW[N,K] (+)= (dy*keepscale)^T x by split-K fp32 atomics, db[N] (+)= column sums of dy, the
+    latter fused into the same launch.  With W (and b) given and direct accumulation active the
+    sums go straight into W.grad / b.grad and (None, None) is returned."""
     M, N = dy.shape
     K = x.shape[1]
-    dW = torch.zeros((N, K), device=dy.device, dtype=torch.float32)
+    direct = _direct(W) and (not want_bias or _direct(b))
+    if direct:
+        dW = _sink[0].target(W)
+        db = _sink[0].target(b) if want_bias else None
+    else:
+        dW = torch.zeros((N, K), device=dy.device, dtype=torch.float32)
+        db = torch.zeros((N,), device=dy.device, dtype=torch.float32) if want_bias else None
     flags = GEMM_A_KMAJOR | GEMM_B_KMAJOR | GEMM_SPLITK | (GEMM_A_DROPMASK if a_drop is not None else 0)
-    gemm(dy, dy.stride(0), x, x.stride(0), dW, K, N, K, M, flags=flags, drop=a_drop)
-    db = colsum(dy, a_drop) if want_bias else None
+    gemm(dy, dy.stride(0), x, x.stride(0), dW, K, N, K, M, flags=flags, drop=a_drop, a_rowsum=db)
+    if direct:
+        _sink[0].done(W)
+        if want_bias:
+            _sink[0].done(b)
+        return None, None
     return dW, db
 
 
@@ -151,12 +222,21 @@ def layernorm_fwd(x2, a, b, eps=1e-6):
     return y
 
 
-def layernorm_bwd(x2, a, dy, add_to=None, eps=1e-6):
+def layernorm_bwd(x2, a, dy, add_to=None, eps=1e-6, a_param=None, b_param=None):
     dx = torch.empty_like(x2)
-    dab = torch.zeros((2, x2.shape[1]), device=x2.device, dtype=torch.float32)
-    call("tvae_layernorm_bwd", _p(x2), _p(a), _p(dy), _p(add_to), _p(dx), _p(dab[0]), _p(dab[1]),
+    direct = _direct(a_param, b_param)
+    if direct:
+        da, db = _sink[0].target(a_param), _sink[0].target(b_param)
+    else:
+        dab = torch.zeros((2, x2.shape[1]), device=x2.device, dtype=torch.float32)
+        da, db = dab[0], dab[1]
+    call("tvae_layernorm_bwd", _p(x2), _p(a), _p(dy), _p(add_to), _p(dx), _p(da), _p(db),
          x2.shape[0], x2.shape[1], eps, _stream())
-    return dx, dab[0], dab[1]
+    if direct:
+        _sink[0].done(a_param)
+        _sink[0].done(b_param)
+        return dx, None, None
+    return dx, da, db
 
 
 class MaskSpec:
@@ -233,13 +313,14 @@ class LayerNormFn(torch.autograd.Function):
         _chk(x2, "x")
         y = layernorm_fwd(x2, a, b, eps)
         ctx.save_for_backward(x2, a)
-        ctx.eps = eps
+        ctx.eps, ctx.P = eps, (a, b)
+        _note_use(a, b)
         return y.view(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
         x2, a = ctx.saved_tensors
-        dx, da, db = layernorm_bwd(x2, a, _c(dy).view(x2.shape), None, ctx.eps)
+        dx, da, db = layernorm_bwd(x2, a, _c(dy).view(x2.shape), None, ctx.eps, *ctx.P)
         return dx.view(dy.shape), da, db, None
 
 
@@ -261,7 +342,8 @@ class LinearFn(torch.autograd.Function):
         _chk(x2, "x")
         y = linear_fwd(x2, W, b, relu=relu)
         ctx.save_for_backward(x2, W, y if relu else None)
-        ctx.relu, ctx.has_bias, ctx.xshape = relu, b is not None, x.shape
+        ctx.relu, ctx.has_bias, ctx.xshape, ctx.P = relu, b is not None, x.shape, (W, b)
+        _note_use(W, b)
         return y.view(x.shape[:-1] + (W.shape[0],))
 
     @staticmethod
@@ -271,7 +353,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.relu:
             dy2 = relu_mask(dy2, y)
         dx = linear_dgrad(dy2, W).view(ctx.xshape) if ctx.needs_input_grad[0] else None
-        dW, db = linear_wgrad(dy2, x2, want_bias=ctx.has_bias)
+        dW, db = linear_wgrad(dy2, x2, want_bias=ctx.has_bias, W=ctx.P[0], b=ctx.P[1])
         return dx, dW, db, None
 
 
@@ -290,7 +372,8 @@ class EmbedFn(torch.autograd.Function):
             raise _lib.TvaeError("sequence length %d exceeds positional table %d" % (L, pe2.shape[0]))
         call("tvae_embed_fwd", _p(ids), _p(lut), _p(pe2), _p(out), B, L, d, vocab, r, s, p, _stream())
         ctx.save_for_backward(ids)
-        ctx.drop, ctx.shape = drop, (vocab, d)
+        ctx.drop, ctx.shape, ctx.P = drop, (vocab, d), lut
+        _note_use(lut)
         return out
 
     @staticmethod
@@ -298,9 +381,13 @@ class EmbedFn(torch.autograd.Function):
         (ids,) = ctx.saved_tensors
         vocab, d = ctx.shape
         B, L = ids.shape
-        dlut = torch.zeros((vocab, d), device=dout.device, dtype=torch.float32)
+        direct = _direct(ctx.P)
+        dlut = _sink[0].target(ctx.P) if direct else torch.zeros((vocab, d), device=dout.device, dtype=torch.float32)
         r, s, p = _drop_args(ctx.drop)
         call("tvae_embed_bwd", _p(ids), _p(_c(dout)), _p(dlut), B, L, d, vocab, r, s, p, _stream())
+        if direct:
+            _sink[0].done(ctx.P)
+            return None, None, None, None
         return None, dlut, None, None
 
 
@@ -359,6 +446,8 @@ class AttnSublayerFn(torch.autograd.Function):
         y = linear_fwd(o, Wo, bo, residual=x2, drop=drop_res)
         ctx.save_for_backward(x2, n, kv_in if mem is not None else None, q, k, v, o, lse, ln_a, Wq, Wk, Wv, Wo)
         ctx.meta = (B, h, Lq, Lk, dk, spec, drop_attn, drop_res, eps, mem is not None)
+        ctx.P = (ln_a, ln_b, Wq, bq, Wk, bk, Wv, bv, Wo, bo)
+        _note_use(*ctx.P)
         return y.view(B, Lq, d)
 
     @staticmethod
@@ -368,12 +457,13 @@ class AttnSublayerFn(torch.autograd.Function):
         d = h * dk
         dy2 = _c(dy).view(-1, d)
         do = linear_dgrad(dy2, Wo, a_drop=drop_res)
-        dWo, dbo = linear_wgrad(dy2, o, a_drop=drop_res)
+        pa, pb, pWq, pbq, pWk, pbk, pWv, pbv, pWo, pbo = ctx.P
+        dWo, dbo = linear_wgrad(dy2, o, a_drop=drop_res, W=pWo, b=pbo)
         dq, dkk, dv = attn_bwd(q, k, v, o, do, lse, B, h, Lq, Lk, dk, spec, drop_attn)
         kv_in = memv if cross else n
-        dWq, dbq = linear_wgrad(dq, n)
-        dWk, dbk = linear_wgrad(dkk, kv_in)
-        dWv, dbv = linear_wgrad(dv, kv_in)
+        dWq, dbq = linear_wgrad(dq, n, W=pWq, b=pbq)
+        dWk, dbk = linear_wgrad(dkk, kv_in, W=pWk, b=pbk)
+        dWv, dbv = linear_wgrad(dv, kv_in, W=pWv, b=pbv)
         dn = linear_dgrad(dq, Wq)
         if cross:
             dmem = linear_dgrad(dkk, Wk)
@@ -383,7 +473,7 @@ class AttnSublayerFn(torch.autograd.Function):
             linear_dgrad(dkk, Wk, out=dn, accumulate=True)
             linear_dgrad(dv, Wv, out=dn, accumulate=True)
             dmem = None
-        dx, da, db = layernorm_bwd(x2, ln_a, dn, add_to=dy2, eps=eps)
+        dx, da, db = layernorm_bwd(x2, ln_a, dn, add_to=dy2, eps=eps, a_param=pa, b_param=pb)
         return (dx.view(B, Lq, d), dmem, da, db, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo,
                 None, None, None, None, None)
 
@@ -401,6 +491,8 @@ class FFNSublayerFn(torch.autograd.Function):
         y = linear_fwd(hmid, W2, b2, residual=x2, drop=drop_res)
         ctx.save_for_backward(x2, n, hmid, ln_a, W1, W2)
         ctx.meta = (drop_ff, drop_res, eps, shp)
+        ctx.P = (ln_a, ln_b, W1, b1, W2, b2)
+        _note_use(*ctx.P)
         return y.view(shp)
 
     @staticmethod
@@ -408,13 +500,14 @@ class FFNSublayerFn(torch.autograd.Function):
         x2, n, hmid, ln_a, W1, W2 = ctx.saved_tensors
         drop_ff, drop_res, eps, shp = ctx.meta
         dy2 = _c(dy).view(x2.shape)
-        dW2, db2 = linear_wgrad(dy2, hmid, a_drop=drop_res)
+        pa, pb, pW1, pb1, pW2, pb2 = ctx.P
+        dW2, db2 = linear_wgrad(dy2, hmid, a_drop=drop_res, W=pW2, b=pb2)
         # hmid = keepscale * relu(pre): hmid > 0 <=> kept and pre > 0, so one mask + one scale
         sc = 1.0 / (1.0 - drop_ff.p) if drop_ff is not None else 1.0
         dh = linear_dgrad(dy2, W2, relumask=hmid, alpha=sc, a_drop=drop_res)
-        dW1, db1 = linear_wgrad(dh, n)
+        dW1, db1 = linear_wgrad(dh, n, W=pW1, b=pb1)
         dn = linear_dgrad(dh, W1)
-        dx, da, db = layernorm_bwd(x2, ln_a, dn, add_to=dy2, eps=eps)
+        dx, da, db = layernorm_bwd(x2, ln_a, dn, add_to=dy2, eps=eps, a_param=pa, b_param=pb)
         return dx.view(shp), da, db, dW1, db1, dW2, db2, None, None, None
 
 
@@ -467,9 +560,10 @@ def _conv_gemm(xin, rows_total, Cin, wp, bias, k, relu):
 def _conv_wgrad(dy_rows, xin, rows_total, Cin, Cout, k):
     """dwp[co, j*Cin+ci] = sum_r dy[r, co] x[r+j, ci] over r < rows_total-(k-1) (split-K atomics)."""
     dwp = torch.zeros((Cout, k * Cin), device=xin.device, dtype=torch.float32)
+    db = torch.zeros((Cout,), device=xin.device, dtype=torch.float32)     # bias grad, fused row sums
     gemm(dy_rows, Cout, xin, Cin, dwp, k * Cin, Cout, k * Cin, rows_total - (k - 1),
-         flags=GEMM_A_KMAJOR | GEMM_B_KMAJOR | GEMM_SPLITK)
-    return dwp
+         flags=GEMM_A_KMAJOR | GEMM_B_KMAJOR | GEMM_SPLITK, a_rowsum=db)
+    return dwp, db
 
 
 def _conv_dgrad(dy_padded, rows_total, Cout, w_dgrad, Cin, k):
@@ -519,9 +613,8 @@ class ConvBottleneckFn(torch.autograd.Function):
             buf = torch.zeros(((k - 1) + B * L, Cout), device=dy.device, dtype=torch.float32)
             dconv = buf[k - 1:]
             call("tvae_pool_relu_bwd", _p(conv), _p(dy), _p(dconv), B, L, Lconv, Cout, int(li == 2), _stream())
-            dwp = _conv_wgrad(dconv, xin, B * L, Cin, Cout, k)
+            dwp, grads[2 * li + 1] = _conv_wgrad(dconv, xin, B * L, Cin, Cout, k)
             grads[2 * li] = _unpack_dw(dwp, W[li].shape, Cout, Cin, k, False)
-            grads[2 * li + 1] = colsum(dconv)
             if li > 0 or ctx.needs_input_grad[0]:
                 wd = _pack_w(W[li], Cin, Cout, k, True)       # (Cin, k*Cout): wd[ci][j*Cout+co] = W[co][ci][k-1-j]
                 dy = _conv_dgrad(buf, B * L, Cout, wd, Cin, k)
@@ -576,9 +669,8 @@ class DeconvBottleneckFn(torch.autograd.Function):
             dyr = buf[k - 1:]
             call("tvae_upsample_bwd", _p(dup), _p(y), _p(dyr), Lup, 0, B, Lout, Cout, d_stride, d_lpad, d_Lup,
                  _stream())
-            dwp = _conv_wgrad(dyr, up, B * Lup, Cin, Cout, k)
+            dwp, grads[2 * li + 1] = _conv_wgrad(dyr, up, B * Lup, Cin, Cout, k)
             grads[2 * li] = _unpack_dw(dwp, W[li].shape, Cout, Cin, k, True)
-            grads[2 * li + 1] = colsum(dyr)
             if li > 0 or ctx.needs_input_grad[0]:
                 wd = _pack_w(W[li], Cin, Cout, k, False)                 # wd[ci][j*Cout+co] = W[ci][co][j]
                 dup = _conv_dgrad(buf, B * Lup, Cout, wd, Cin, k)        # gradient of the zero-stuffed input
@@ -593,16 +685,18 @@ class DeconvBottleneckFn(torch.autograd.Function):
 
 # ----------------------------------------------------------------------------- loss
 def loss_fwd_bwd(tokens, logits, weights, pred_len, mu, logvar, pred_prop, true_prop, beta, pad_idx,
-                 want_grads=True, true_len=None):
+                 want_grads=True, true_len=None, n_groups=1):
     """trans_vae_loss (reference loss.py:23-38) + its gradients in two launches.
-    Returns (out5 device tensor [total,bce,bce_mask,kld,mse], grads dict)."""
+    Returns (out5 device tensor [total,bce,bce_mask,kld,mse] -- (n_groups, 5) if n_groups > 1 --,
+    grads dict).  n_groups > 1: the batch is that many consecutive chunks, each normalised on its
+    own; gradients are those of the sum of the chunk losses (the reference's accumulation)."""
     B, Lp1 = tokens.shape
     L = Lp1 - 1
     n_cls = logits.shape[-1]
     lg = _c(logits).view(B * L, n_cls)
     dev = lg.device
-    out5 = torch.empty(5, device=dev, dtype=torch.float32)
-    scratch = torch.empty(8, device=dev, dtype=torch.float32)
+    out5 = torch.empty((n_groups, 5), device=dev, dtype=torch.float32)
+    scratch = torch.empty(8 * n_groups, device=dev, dtype=torch.float32)
     g = {}
     if want_grads:
         g["logits"] = torch.empty_like(lg)
@@ -614,10 +708,10 @@ def loss_fwd_bwd(tokens, logits, weights, pred_len, mu, logvar, pred_prop, true_
     tp = None if pred_prop is None else _c(true_prop.to(torch.float32)).view(-1)
     tl = None if true_len is None else _c(true_len.long()).view(-1)
     call("tvae_loss_fwd_bwd", _p(_c(tokens)), _p(lg), lg.stride(0), _p(weights), _p(_c(pred_len)), _p(_c(mu)),
-         _p(_c(logvar)), _p(pp), _p(tp), _p(tl), float(beta), B, L, n_cls, pred_len.shape[1], mu.shape[1], int(pad_idx),
+         _p(_c(logvar)), _p(pp), _p(tp), _p(tl), float(beta), B, L, n_cls, pred_len.shape[1], mu.shape[1], int(pad_idx), int(n_groups),
          _p(out5), _p(g.get("logits")), _p(g.get("pred_len")), _p(g.get("mu")), _p(g.get("logvar")),
          _p(g.get("pred_prop")), _p(scratch), _stream())
-    return out5, g
+    return (out5 if n_groups > 1 else out5[0]), g
 
 
 class LossFn(torch.autograd.Function):

@@ -39,7 +39,7 @@ class GradArena:
             if off - bstart >= target or p is order[-1]:
                 bi = len(self.buckets)
                 for q in members:
-                    self.bucket_of[id(q)] = bi
+                    self.bucket_of[q.data_ptr()] = bi
                 self.buckets.append((bstart, off, len(members)))
                 bstart, members = off, []
         self.params = order
@@ -58,6 +58,12 @@ class DataParallel:
         self._armed = False
         self._pending = []
         self._count = [0] * len(self.arena.buckets)
+        self._launched = set()
+        # two routes tell us that a parameter's gradient is final for this step: the kernels that
+        # accumulate straight into param.grad report through the sink; the few parameters whose
+        # gradient still travels through autograd (conv / deconv kernels) through a hook
+        from . import ops
+        self.sink = ops.GradSink(on_complete=self._hook if overlap else None)
         if overlap:
             for p in self.arena.params:
                 p.register_post_accumulate_grad_hook(self._hook)
@@ -72,13 +78,16 @@ class DataParallel:
     def _hook(self, p):
         if not self._armed:
             return
-        bi = self.arena.bucket_of[id(p)]
+        bi = self.arena.bucket_of.get(p.data_ptr())
+        if bi is None:
+            return
         self._count[bi] += 1
-        if self._count[bi] == self.arena.buckets[bi][2]:
+        if self._count[bi] >= self.arena.buckets[bi][2] and bi not in self._launched:
             self._launch(bi)
 
     def _launch(self, bi):
         s, e, _ = self.arena.buckets[bi]
+        self._launched.add(bi)
         self._pending.append(dist.all_reduce(self.arena.flat[s:e], op=dist.ReduceOp.SUM, async_op=True))
 
     def arm(self):
@@ -86,16 +95,15 @@ class DataParallel:
         self._armed = True
         self._count = [0] * len(self.arena.buckets)
         self._pending = []
+        self._launched = set()
 
     def finish(self):
         "after the last backward: reduce whatever was not launched from hooks, wait for all buckets"
-        if not self.overlap or not self._armed:
-            for bi in range(len(self.arena.buckets)):
+        if not self._armed:
+            self._pending, self._launched = [], set()
+        for bi in range(len(self.arena.buckets)):
+            if bi not in self._launched:                  # not launched from a hook (or overlap off)
                 self._launch(bi)
-        else:
-            for bi, c in enumerate(self._count):
-                if c != self.arena.buckets[bi][2]:        # a parameter got no gradient this step
-                    self._launch(bi)
         for w in self._pending:
             w.wait()
         self._armed = False

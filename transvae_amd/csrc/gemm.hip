@@ -22,7 +22,8 @@ constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDS_KC = BK + 4;    // [row][k] stride (floats)
 constexpr int LDS_KM = BM + 4;    // [k][row] stride (floats)
 constexpr int TILE_FLOATS = BM * LDS_KC;  // 4608 >= BK*LDS_KM (4224)
-constexpr int LDS_BF = BK + 8;    // bf16 [row][k] stride (elements): 80 B rows, conflict-free b128
+constexpr int LDS_BF = BK + 8;
+constexpr int FLAG_VEC_EPILOGUE = 1 << 20;   // internal: float4 epilogue through LDS (set by the host wrapper)    // bf16 [row][k] stride (elements): 80 B rows, conflict-free b128
 
 struct GemmArgs {
   const float* A; const float* B; float* C; const float* bias; const float* res;
@@ -40,43 +41,59 @@ __device__ inline unsigned short f2bf(float f) {
 }
 
 // ---- global -> register staging of one 128x32 operand tile (4 float4 per thread) ----------
-template <bool KM, bool ALIGNED, bool DROP>
+// stage_load only ISSUES the loads (out-of-range pieces read the always-valid first float4);
+// stage_fix, called after the MFMAs of the current tile, zeroes those pieces and applies the
+// dropout keep-scale.  Touching the loaded registers any earlier would put the s_waitcnt vmcnt
+// in front of the MFMA block and expose the full memory latency once per k-tile.
+template <bool KM, bool ALIGNED>
 __device__ inline void stage_load(float4 (&st)[4], const float* __restrict__ P, int ld,
-                                  int row0, int nrows, int k0, int kend, int tid,
-                                  const DropCfg& dc, int dropM, int dropK) {
+                                  int row0, int nrows, int k0, int kend, int tid) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     int f = tid + 256 * j;
     int row, k;
     if (!KM) { row = f >> 3; k = (f & 7) * 4; } else { k = f >> 5; row = (f & 31) * 4; }
     int gr = row0 + row, gk = k0 + k;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ALIGNED) {
-      if (gr < nrows && gk < kend) {
-        const float* src = KM ? (P + (size_t)gk * ld + gr) : (P + (size_t)gr * ld + gk);
-        v = *reinterpret_cast<const float4*>(src);
-      }
+      const bool ok = gr < nrows && gk < kend;
+      const size_t off = KM ? ((size_t)gk * ld + gr) : ((size_t)gr * ld + gk);
+      st[j] = *reinterpret_cast<const float4*>(P + (ok ? off : 0));
     } else {
       float t[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         int rr = KM ? gr + e : gr, kk = KM ? gk : gk + e;
-        t[e] = (rr < nrows && kk < kend) ? (KM ? P[(size_t)kk * ld + rr] : P[(size_t)rr * ld + kk]) : 0.f;
+        const bool ok = rr < nrows && kk < kend;
+        t[e] = P[ok ? (KM ? (size_t)kk * ld + rr : (size_t)rr * ld + kk) : 0];
       }
-      v = make_float4(t[0], t[1], t[2], t[3]);
+      st[j] = make_float4(t[0], t[1], t[2], t[3]);
     }
-    if (DROP) {
-      // element (m,k) of A carries the keep-scale of the dropped-out tensor it is the gradient of
-      float* pv = reinterpret_cast<float*>(&v);
+  }
+}
+
+template <bool KM, bool DROP>
+__device__ inline void stage_fix(float4 (&st)[4], int row0, int nrows, int k0, int kend, int tid,
+                                 const DropCfg& dc, int dropM, int dropK) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        int rr = KM ? gr + e : gr, kk = KM ? gk : gk + e;
+  for (int j = 0; j < 4; ++j) {
+    int f = tid + 256 * j;
+    int row, k;
+    if (!KM) { row = f >> 3; k = (f & 7) * 4; } else { k = f >> 5; row = (f & 31) * 4; }
+    int gr = row0 + row, gk = k0 + k;
+    float* pv = reinterpret_cast<float*>(&st[j]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int rr = KM ? gr + e : gr, kk = KM ? gk : gk + e;
+      const bool ok = rr < nrows && kk < kend;
+      float v = ok ? pv[e] : 0.f;
+      if (DROP) {
+        // element (m,k) of A carries the keep-scale of the dropped-out tensor it is the gradient of
         uint32_t idx = KM ? (uint32_t)kk * (uint32_t)dropM + (uint32_t)rr
                           : (uint32_t)rr * (uint32_t)dropK + (uint32_t)kk;
-        pv[e] *= drop_scale(dc, idx);
+        v *= drop_scale(dc, idx);
       }
+      pv[e] = v;
     }
-    st[j] = v;
   }
 }
 
@@ -121,7 +138,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, hh = lane >> 5;
   const int ntn = (g.N + BN - 1) / BN;
-  const int tile_n = blockIdx.x % ntn, tile_m = blockIdx.x / ntn;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (id % 8 shares an L2),
+  // so give each XCD a CONTIGUOUS run of tiles -- the ntn column tiles that re-read one A row
+  // panel then hit the same L2 instead of fetching the panel once per XCD.  (Bijective for any
+  // grid size; placement is a speed matter only.)
+  int wgid;
+  {
+    const int nwg = gridDim.x, id = blockIdx.x, q = nwg >> 3, rr = nwg & 7, xcd = id & 7;
+    wgid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (id >> 3);
+  }
+  const int tile_n = wgid % ntn, tile_m = wgid / ntn;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int kbeg = blockIdx.z * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
@@ -149,8 +175,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   auto tileB = [&](int buf) { return lds + (buf * 2 + 1) * TILE_FLOATS; };
 
   if (nkt > 0) {
-    stage_load<A_KM, ALIGNED, DROP>(sa, g.A, g.lda, m0, g.M, kbeg, kend, tid, dc, g.M, g.K);
-    stage_load<B_KM, ALIGNED, false>(sb, g.B, g.ldb, n0, g.N, kbeg, kend, tid, nodrop, 0, 0);
+    stage_load<A_KM, ALIGNED>(sa, g.A, g.lda, m0, g.M, kbeg, kend, tid);
+    stage_load<B_KM, ALIGNED>(sb, g.B, g.ldb, n0, g.N, kbeg, kend, tid);
+    stage_fix<A_KM, DROP>(sa, m0, g.M, kbeg, kend, tid, dc, g.M, g.K);
+    stage_fix<B_KM, false>(sb, n0, g.N, kbeg, kend, tid, nodrop, 0, 0);
     if (do_rowsum) add_rowsum();
     if (BF16) {
       stage_store_bf16<A_KM>(sa, reinterpret_cast<unsigned short*>(tileA(0)), tid);
@@ -167,8 +195,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const bool more = (kt + 1 < nkt);
     if (more) {
       int k0 = kbeg + (kt + 1) * BK;
-      stage_load<A_KM, ALIGNED, DROP>(sa, g.A, g.lda, m0, g.M, k0, kend, tid, dc, g.M, g.K);
-      stage_load<B_KM, ALIGNED, false>(sb, g.B, g.ldb, n0, g.N, k0, kend, tid, nodrop, 0, 0);
+      stage_load<A_KM, ALIGNED>(sa, g.A, g.lda, m0, g.M, k0, kend, tid);
+      stage_load<B_KM, ALIGNED>(sb, g.B, g.ldb, n0, g.N, k0, kend, tid);
     }
     if (!BF16) {
       const float* TA = tileA(buf);
@@ -232,6 +260,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], b[j][ks], acc[i][j], 0, 0, 0);
     }
     if (more) {
+      const int k0 = kbeg + (kt + 1) * BK;
+      stage_fix<A_KM, DROP>(sa, m0, g.M, k0, kend, tid, dc, g.M, g.K);
+      stage_fix<B_KM, false>(sb, n0, g.N, k0, kend, tid, nodrop, 0, 0);
       if (do_rowsum) add_rowsum();     // after the MFMAs: the loads have landed by now
       if (BF16) {
         stage_store_bf16<A_KM>(sa, reinterpret_cast<unsigned short*>(tileA(buf ^ 1)), tid);
@@ -261,6 +292,71 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const bool splitk = g.flags & TVAE_GEMM_SPLITK, relumask = g.flags & 64;
   DropCfg de = drop_cfg((g.flags & TVAE_GEMM_A_DROPMASK) ? nullptr : g.rng, g.site, g.p);
   const bool lead = (blockIdx.z == 0);
+  if (g.flags & FLAG_VEC_EPILOGUE) {
+    // Row-per-lane accumulator stores are issue-bound (64 dword stores per lane).  Turn the wave's
+    // 64x64 tile through its own LDS slab instead and leave as 16 float4 per lane: 16 lanes cover
+    // one 256-byte row segment, residual / saved-activation reads are float4 too.
+    if (do_rowsum) __syncthreads();
+    constexpr int ES = 68;
+    float* T = lds + wave * (64 * ES);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) T[(32 * i + crow(q, hh)) * ES + 32 * j + r] = acc[i][j][q];
+    const int c = (lane & 15) * 4;
+    const int gcol = n0 + wn * 64 + c;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.bias && gcol < g.N) bv = *reinterpret_cast<const float4*>(g.bias + gcol);
+    const float* __restrict__ aux = g.res;      // residual or saved activation; must not alias C
+    const bool need_aux = (aux != nullptr);
+    const bool col_ok = gcol < g.N;
+    for (int it0 = 0; it0 < 16; it0 += 4) {
+      // batch of 4 row segments: issue every global read first, then compute, then store
+      float4 m[4], old[4], v[4];
+      bool ok[4];
+      size_t coff[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rl = (it0 + u) * 4 + (lane >> 4);
+        const int grow = m0 + wm * 64 + rl;
+        ok[u] = col_ok && grow < g.M;
+        coff[u] = (size_t)(ok[u] ? grow : 0) * g.ldc + (col_ok ? gcol : 0);
+        v[u] = *reinterpret_cast<const float4*>(&T[rl * ES + c]);
+        m[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        old[u] = m[u];
+        if (need_aux) m[u] = *reinterpret_cast<const float4*>(aux + (size_t)(ok[u] ? grow : 0) * g.ldr + (col_ok ? gcol : 0));
+        if (accum) old[u] = *reinterpret_cast<const float4*>(g.C + coff[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int grow = m0 + wm * 64 + (it0 + u) * 4 + (lane >> 4);
+        float o[4] = {v[u].x * g.alpha + bv.x, v[u].y * g.alpha + bv.y, v[u].z * g.alpha + bv.z, v[u].w * g.alpha + bv.w};
+        const float mm[4] = {m[u].x, m[u].y, m[u].z, m[u].w};
+        if (relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+        }
+        if (relumask) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = mm[e] > 0.f ? o[e] : 0.f;
+        } else {
+          if (de.on) {
+            const uint32_t base = (uint32_t)grow * (uint32_t)g.N + (uint32_t)gcol;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] *= drop_scale(de, base + e);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] += mm[e];      // zero when there is no residual
+        }
+        if (ok[u])
+          *reinterpret_cast<float4*>(g.C + coff[u]) =
+              make_float4(o[0] + old[u].x, o[1] + old[u].y, o[2] + old[u].z, o[3] + old[u].w);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -338,6 +434,9 @@ extern "C" int tvae_gemm(const float* A, int lda, const float* B, int ldb, float
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.M = M; g.N = N; g.K = K;
   g.alpha = alpha; g.flags = flags; g.rng = rng; g.site = site; g.p = p_drop;
   g.a_rowsum = a_rowsum;
+  if (!(flags & TVAE_GEMM_SPLITK) && N % 4 == 0 && ldc % 4 == 0 && aligned16(C) &&
+      (!bias || aligned16(bias)) && (!residual || (ldr % 4 == 0 && aligned16(residual))))
+    g.flags |= FLAG_VEC_EPILOGUE;
   TVAE_CHECK(!a_rowsum || a_km, TVAE_E_SHAPE, "tvae_gemm: a_rowsum needs a k-major A (wgrad form)");
   int tiles = cdiv(M, BM) * cdiv(N, BN);
   int splits = 1;

@@ -1,0 +1,56 @@
+"""Dump the attention weights of a trained TransVAE for a set of molecules (flags: scripts/parsers.py;
+behaviour and output files: reference scripts/attention.py:17-82): `<save_path>_self_attn.npy`
+(n, 4, 4, 127, 127) = 3 encoder layers + the decoder's final_encode layer, `<save_path>_src_attn.npy`
+(n, 3, 4, 126, 127)."""
+import os
+import sys
+
+import numpy as np
+import pandas as pd
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from scripts.parsers import attn_parser, require_transformer  # noqa: E402
+from transvae_amd.data import make_src_mask, make_std_mask, vae_data_gen  # noqa: E402
+from transvae_amd.trans_models import TransVAE  # noqa: E402
+
+
+@torch.no_grad()
+def calc_attention(args):
+    require_transformer(args)
+    vae = TransVAE(load_fn=args.model_ckpt)
+    frame = pd.read_csv(args.mols)
+    mols = frame.sample(args.n_samples).to_numpy() if args.shuffle else frame.to_numpy()[:args.n_samples, :]
+    data = vae_data_gen(mols, props=None, char_dict=vae.params['CHAR_DICT'])
+    n_batches = len(data) // args.batch_size
+    chunk = args.batch_size // args.batch_chunks
+    save_path = args.save_path
+    if save_path is None:
+        os.makedirs('attn_wts', exist_ok=True)
+        save_path = 'attn_wts/{}'.format(vae.name)
+
+    vae.model.eval()
+    dev = next(vae.model.parameters()).device
+    n = n_batches * args.batch_size
+    self_attn = torch.empty((n, 4, 4, 127, 127))
+    src_attn = torch.empty((n, 3, 4, 126, 127))
+    self_attn.zero_()           # rows past batch_chunks*chunk of a batch stay zero (uninitialised in the reference)
+    src_attn.zero_()
+    starts = [j * args.batch_size + i * chunk for j in range(n_batches) for i in range(args.batch_chunks)]
+    for start in starts:
+        rows = torch.as_tensor(np.asarray(data[start:start + chunk]))[:, :-1].to(dev)
+        src = rows.long()
+        tgt = src[:, :-1]
+        src_mask, tgt_mask = make_src_mask(src, vae.pad_idx), make_std_mask(tgt, vae.pad_idx)
+        mem, _, _, _, enc_wts = vae.model.encoder.forward_w_attn(vae.model.src_embed(src), src_mask)
+        _, deconv_wts, src_wts = vae.model.decoder.forward_w_attn(vae.model.tgt_embed(tgt), mem, src_mask, tgt_mask)
+        for k, w in enumerate(list(enc_wts) + list(deconv_wts)):
+            self_attn[start:start + chunk, k] = w.cpu()
+        for k, w in enumerate(src_wts):
+            src_attn[start:start + chunk, k] = w.cpu()
+    np.save(save_path + '_self_attn.npy', self_attn.numpy())
+    np.save(save_path + '_src_attn.npy', src_attn.numpy())
+
+
+if __name__ == '__main__':
+    calc_attention(attn_parser().parse_args())

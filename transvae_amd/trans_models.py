@@ -639,8 +639,23 @@ class VAEShell():
         "Train and validate (reference :126-352: same batching, CSV log rows and checkpoint cadence)"
         train_data = self.data_gen(train_mols, train_props, char_dict=self.params['CHAR_DICT'])
         val_data = self.data_gen(val_mols, val_props, char_dict=self.params['CHAR_DICT'])
-        loader = lambda d: torch.utils.data.DataLoader(d, batch_size=self.params['BATCH_SIZE'], shuffle=True,
-                                                       num_workers=0, pin_memory=self.use_gpu, drop_last=True)
+        # one process per GPU (torch.distributed initialised by the launcher): every rank takes its own
+        # shard of each epoch's shuffle and BATCH_SIZE is per rank; rank 0 logs and writes checkpoints
+        import torch.distributed as dist
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        rank = dist.get_rank() if world > 1 else 0
+        dp = None
+        if world > 1:
+            from .parallel import DataParallel
+            dp = DataParallel(self)
+            log, save = log and rank == 0, save and rank == 0
+
+        def loader(d):
+            sampler = None
+            if world > 1:
+                sampler = torch.utils.data.distributed.DistributedSampler(d, world, rank, shuffle=True, drop_last=True)
+            return torch.utils.data.DataLoader(d, batch_size=self.params['BATCH_SIZE'], shuffle=sampler is None,
+                                               sampler=sampler, num_workers=0, pin_memory=self.use_gpu, drop_last=True)
         train_iter, val_iter = loader(train_data), loader(val_data)
         self.chunk_size = self.params['BATCH_SIZE'] // self.params['BATCH_CHUNKS']
         if save_freq is None:
@@ -670,12 +685,19 @@ class VAEShell():
                         f.write(','.join(str(v) for v in row) + '\n')
             return np.mean(means) if means else float('nan')
 
+        train_fn = self.train_step if dp is None else (lambda data, beta: self.train_step(data, beta, dp=dp))
         for epoch in range(epochs):
             self.model.train()
             beta = kl_annealer(epoch)
-            train_loss = run(train_iter, self.train_step, 'train', beta, True)
+            if world > 1:
+                train_iter.sampler.set_epoch(self.n_epochs)
+            train_loss = run(train_iter, train_fn, 'train', beta, True)
             self.model.eval()
             val_loss = run(val_iter, self.eval_step, 'test', beta, False)
+            if world > 1:                   # every rank must take the same best-checkpoint decision
+                both = torch.tensor([train_loss, val_loss], dtype=torch.float64, device=self._device())
+                dist.all_reduce(both)
+                train_loss, val_loss = (both / world).tolist()
             self.n_epochs += 1
             print('Epoch - {} Train - {} Val - {} KLBeta - {}'.format(self.n_epochs, train_loss, val_loss, beta))
             self.current_state['epoch'] = self.n_epochs

@@ -43,7 +43,7 @@ def time_gemm(M, N, K, dtype_name, iters=20):
     x = torch.randn(M, K, device="cuda")
     w = torch.randn(N, K, device="cuda") * 0.05
     b = torch.zeros(N, device="cuda")
-    out = torch.empty(M, N, device="cuda")
+    out = ops.rows_buffer(M, N, "cuda")              # the padded-row buffer the model itself allocates
     for _ in range(3):
         ops.linear_fwd(x, w, b, relu=True, out=out)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

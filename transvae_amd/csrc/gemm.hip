@@ -14,16 +14,27 @@
 // stride 36 floats makes the b128 fragment reads bank-conflict-free); operands whose layout
 // is m-contiguous ("k-major": weight for dgrad, both operands for wgrad) are staged as
 // [k][row] (+4) and read with conflict-free ds_read_b32.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int LDS_KC = BK + 4;    // [row][k] stride (floats)
+constexpr int BM = 128, BN = 128;
 constexpr int LDS_KM = BM + 4;    // [k][row] stride (floats)
-constexpr int TILE_FLOATS = BM * LDS_KC;  // 4608 >= BK*LDS_KM (4224)
-constexpr int LDS_BF = BK + 8;
-constexpr int FLAG_VEC_EPILOGUE = 1 << 20;   // internal: float4 epilogue through LDS (set by the host wrapper)    // bf16 [row][k] stride (elements): 80 B rows, conflict-free b128
+constexpr int FLAG_VEC_EPILOGUE = 1 << 20;   // internal: float4 epilogue through LDS (set by the host wrapper)
+
+// The k-depth of a tile is a template parameter: BK = 32 halves the barrier count, BK = 16 halves
+// LDS and the fragment registers so that three workgroups share a CU instead of two (the prologue
+// and epilogue of one tile then overlap the MFMA loops of two others -- with K = 256 = d_model
+// on most launches a tile has only 8..16 k-steps, so that overlap is what sets the rate).
+template <int BK>
+struct Tile {
+  static constexpr int KC = BK + 4;                 // [row][k] stride (floats): conflict-free b128 fragment reads
+  static constexpr int BF = BK + 8;                 // bf16 [row][k] stride (elements)
+  static constexpr int FLOATS = (BM * KC > BK * LDS_KM) ? BM * KC : BK * LDS_KM;
+  static constexpr int NJ = BK / 8;                 // float4 per thread per operand tile
+  static constexpr int HK = BK / 2;                 // k values owned by one lane half
+};
 
 struct GemmArgs {
   const float* A; const float* B; float* C; const float* bias; const float* res;
@@ -45,14 +56,19 @@ __device__ inline unsigned short f2bf(float f) {
 // stage_fix, called after the MFMAs of the current tile, zeroes those pieces and applies the
 // dropout keep-scale.  Touching the loaded registers any earlier would put the s_waitcnt vmcnt
 // in front of the MFMA block and expose the full memory latency once per k-tile.
-template <bool KM, bool ALIGNED>
-__device__ inline void stage_load(float4 (&st)[4], const float* __restrict__ P, int ld,
+template <int BK, bool KM>
+__device__ inline void stage_pos(int f, int& row, int& k) {
+  if (!KM) { row = f / (BK / 4); k = (f % (BK / 4)) * 4; } else { k = f >> 5; row = (f & 31) * 4; }
+}
+
+template <int BK, bool KM, bool ALIGNED>
+__device__ inline void stage_load(float4 (&st)[BK / 8], const float* __restrict__ P, int ld,
                                   int row0, int nrows, int k0, int kend, int tid) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < BK / 8; ++j) {
     int f = tid + 256 * j;
     int row, k;
-    if (!KM) { row = f >> 3; k = (f & 7) * 4; } else { k = f >> 5; row = (f & 31) * 4; }
+    stage_pos<BK, KM>(f, row, k);
     int gr = row0 + row, gk = k0 + k;
     if (ALIGNED) {
       const bool ok = gr < nrows && gk < kend;
@@ -71,14 +87,14 @@ __device__ inline void stage_load(float4 (&st)[4], const float* __restrict__ P, 
   }
 }
 
-template <bool KM, bool DROP>
-__device__ inline void stage_fix(float4 (&st)[4], int row0, int nrows, int k0, int kend, int tid,
+template <int BK, bool KM, bool DROP>
+__device__ inline void stage_fix(float4 (&st)[BK / 8], int row0, int nrows, int k0, int kend, int tid,
                                  const DropCfg& dc, int dropM, int dropK) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < BK / 8; ++j) {
     int f = tid + 256 * j;
     int row, k;
-    if (!KM) { row = f >> 3; k = (f & 7) * 4; } else { k = f >> 5; row = (f & 31) * 4; }
+    stage_pos<BK, KM>(f, row, k);
     int gr = row0 + row, gk = k0 + k;
     float* pv = reinterpret_cast<float*>(&st[j]);
 #pragma unroll
@@ -97,32 +113,28 @@ __device__ inline void stage_fix(float4 (&st)[4], int row0, int nrows, int k0, i
   }
 }
 
-template <bool KM>
-__device__ inline void stage_store_f32(const float4 (&st)[4], float* __restrict__ T, int tid) {
+template <int BK, bool KM>
+__device__ inline void stage_store_f32(const float4 (&st)[BK / 8], float* __restrict__ T, int tid) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    int f = tid + 256 * j;
-    if (!KM) {
-      int row = f >> 3, k = (f & 7) * 4;
-      *reinterpret_cast<float4*>(&T[row * LDS_KC + k]) = st[j];
-    } else {
-      int k = f >> 5, row = (f & 31) * 4;
-      *reinterpret_cast<float4*>(&T[k * LDS_KM + row]) = st[j];
-    }
+  for (int j = 0; j < BK / 8; ++j) {
+    int row, k;
+    stage_pos<BK, KM>(tid + 256 * j, row, k);
+    if (!KM) *reinterpret_cast<float4*>(&T[row * Tile<BK>::KC + k]) = st[j];
+    else *reinterpret_cast<float4*>(&T[k * LDS_KM + row]) = st[j];
   }
 }
 
-template <bool KM>
-__device__ inline void stage_store_bf16(const float4 (&st)[4], unsigned short* __restrict__ T, int tid) {
+template <int BK, bool KM>
+__device__ inline void stage_store_bf16(const float4 (&st)[BK / 8], unsigned short* __restrict__ T, int tid) {
+  constexpr int LDS_BF = Tile<BK>::BF;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    int f = tid + 256 * j;
+  for (int j = 0; j < BK / 8; ++j) {
+    int row, k;
+    stage_pos<BK, KM>(tid + 256 * j, row, k);
     if (!KM) {
-      int row = f >> 3, k = (f & 7) * 4;
       ushort4 o = make_ushort4(f2bf(st[j].x), f2bf(st[j].y), f2bf(st[j].z), f2bf(st[j].w));
       *reinterpret_cast<ushort4*>(&T[row * LDS_BF + k]) = o;
-    } else {
-      int k = f >> 5, row = (f & 31) * 4;   // transpose on the way in: bf16 tiles are always [row][k]
+    } else {                                // transpose on the way in: bf16 tiles are always [row][k]
       T[(row + 0) * LDS_BF + k] = f2bf(st[j].x);
       T[(row + 1) * LDS_BF + k] = f2bf(st[j].y);
       T[(row + 2) * LDS_BF + k] = f2bf(st[j].z);
@@ -131,8 +143,11 @@ __device__ inline void stage_store_bf16(const float4 (&st)[4], unsigned short* _
   }
 }
 
-template <bool A_KM, bool B_KM, bool ALIGNED, bool BF16, bool DROP>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+template <int BK, bool A_KM, bool B_KM, bool ALIGNED, bool BF16, bool DROP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BK == 16 ? 4 : 2)))
+void gemm_kernel(GemmArgs g) {
+  constexpr int TILE_FLOATS = Tile<BK>::FLOATS, LDS_KC = Tile<BK>::KC, LDS_BF = Tile<BK>::BF;
+  constexpr int NJ = Tile<BK>::NJ, HK = Tile<BK>::HK;
   __shared__ __attribute__((aligned(16))) float lds[2 * 2 * TILE_FLOATS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -161,31 +176,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
 
-  float4 sa[4], sb[4];
+  float4 sa[NJ], sb[NJ];
   DropCfg nodrop = drop_cfg(nullptr, 0, 0.f);
   // fused bias gradient: in k-major staging all four float4 of a thread cover the same 4 rows
   const bool do_rowsum = A_KM && (g.a_rowsum != nullptr) && (tile_n == 0);
   float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
   auto add_rowsum = [&]() {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { rs.x += sa[j].x; rs.y += sa[j].y; rs.z += sa[j].z; rs.w += sa[j].w; }
+    for (int j = 0; j < NJ; ++j) { rs.x += sa[j].x; rs.y += sa[j].y; rs.z += sa[j].z; rs.w += sa[j].w; }
   };
 
   auto tileA = [&](int buf) { return lds + (buf * 2 + 0) * TILE_FLOATS; };
   auto tileB = [&](int buf) { return lds + (buf * 2 + 1) * TILE_FLOATS; };
 
   if (nkt > 0) {
-    stage_load<A_KM, ALIGNED>(sa, g.A, g.lda, m0, g.M, kbeg, kend, tid);
-    stage_load<B_KM, ALIGNED>(sb, g.B, g.ldb, n0, g.N, kbeg, kend, tid);
-    stage_fix<A_KM, DROP>(sa, m0, g.M, kbeg, kend, tid, dc, g.M, g.K);
-    stage_fix<B_KM, false>(sb, n0, g.N, kbeg, kend, tid, nodrop, 0, 0);
+    stage_load<BK, A_KM, ALIGNED>(sa, g.A, g.lda, m0, g.M, kbeg, kend, tid);
+    stage_load<BK, B_KM, ALIGNED>(sb, g.B, g.ldb, n0, g.N, kbeg, kend, tid);
+    stage_fix<BK, A_KM, DROP>(sa, m0, g.M, kbeg, kend, tid, dc, g.M, g.K);
+    stage_fix<BK, B_KM, false>(sb, n0, g.N, kbeg, kend, tid, nodrop, 0, 0);
     if (do_rowsum) add_rowsum();
     if (BF16) {
-      stage_store_bf16<A_KM>(sa, reinterpret_cast<unsigned short*>(tileA(0)), tid);
-      stage_store_bf16<B_KM>(sb, reinterpret_cast<unsigned short*>(tileB(0)), tid);
+      stage_store_bf16<BK, A_KM>(sa, reinterpret_cast<unsigned short*>(tileA(0)), tid);
+      stage_store_bf16<BK, B_KM>(sb, reinterpret_cast<unsigned short*>(tileB(0)), tid);
     } else {
-      stage_store_f32<A_KM>(sa, tileA(0), tid);
-      stage_store_f32<B_KM>(sb, tileB(0), tid);
+      stage_store_f32<BK, A_KM>(sa, tileA(0), tid);
+      stage_store_f32<BK, B_KM>(sb, tileB(0), tid);
     }
   }
   __syncthreads();
@@ -195,64 +210,64 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const bool more = (kt + 1 < nkt);
     if (more) {
       int k0 = kbeg + (kt + 1) * BK;
-      stage_load<A_KM, ALIGNED>(sa, g.A, g.lda, m0, g.M, k0, kend, tid);
-      stage_load<B_KM, ALIGNED>(sb, g.B, g.ldb, n0, g.N, k0, kend, tid);
+      stage_load<BK, A_KM, ALIGNED>(sa, g.A, g.lda, m0, g.M, k0, kend, tid);
+      stage_load<BK, B_KM, ALIGNED>(sb, g.B, g.ldb, n0, g.N, k0, kend, tid);
     }
     if (!BF16) {
       const float* TA = tileA(buf);
       const float* TB = tileB(buf);
-      float a[2][16], b[2][16];
+      // fragments are fetched in sub-steps of 4 k values (one ds_read_b128 per 32-row block and
+      // operand) so that only 16 fragment registers are live beside the 64 accumulators
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        int row = wm * 64 + 32 * i + r;
-        if (!A_KM) {
+      for (int q = 0; q < HK / 4; ++q) {
+        float a[2][4], b[2][4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float4 v = *reinterpret_cast<const float4*>(&TA[row * LDS_KC + 16 * hh + 4 * q]);
-            a[i][4 * q + 0] = v.x; a[i][4 * q + 1] = v.y; a[i][4 * q + 2] = v.z; a[i][4 * q + 3] = v.w;
+        for (int i = 0; i < 2; ++i) {
+          const int row = wm * 64 + 32 * i + r;
+          if (!A_KM) {
+            float4 v = *reinterpret_cast<const float4*>(&TA[row * LDS_KC + HK * hh + 4 * q]);
+            a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;
+          } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) a[i][s] = TA[(HK * hh + 4 * q + s) * LDS_KM + row];
           }
-        } else {
-#pragma unroll
-          for (int s = 0; s < 16; ++s) a[i][s] = TA[(16 * hh + s) * LDS_KM + row];
         }
-      }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        int col = wn * 64 + 32 * j + r;
-        if (!B_KM) {
+        for (int j = 0; j < 2; ++j) {
+          const int col = wn * 64 + 32 * j + r;
+          if (!B_KM) {
+            float4 v = *reinterpret_cast<const float4*>(&TB[col * LDS_KC + HK * hh + 4 * q]);
+            b[j][0] = v.x; b[j][1] = v.y; b[j][2] = v.z; b[j][3] = v.w;
+          } else {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float4 v = *reinterpret_cast<const float4*>(&TB[col * LDS_KC + 16 * hh + 4 * q]);
-            b[j][4 * q + 0] = v.x; b[j][4 * q + 1] = v.y; b[j][4 * q + 2] = v.z; b[j][4 * q + 3] = v.w;
+            for (int s = 0; s < 4; ++s) b[j][s] = TB[(HK * hh + 4 * q + s) * LDS_KM + col];
           }
-        } else {
-#pragma unroll
-          for (int s = 0; s < 16; ++s) b[j][s] = TB[(16 * hh + s) * LDS_KM + col];
         }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
       }
-#pragma unroll
-      for (int s = 0; s < 16; ++s)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
     } else {
       const unsigned short* TA = reinterpret_cast<const unsigned short*>(tileA(buf));
       const unsigned short* TB = reinterpret_cast<const unsigned short*>(tileB(buf));
-      bf16x8 a[2][2], b[2][2];   // [tile][k-step of 16]
+      constexpr int KS = BK / 16;
+      bf16x8 a[2][KS], b[2][KS];   // [tile][k-step of 16]
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
           a[i][ks] = *reinterpret_cast<const bf16x8*>(&TA[(wm * 64 + 32 * i + r) * LDS_BF + 16 * ks + 8 * hh]);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
           b[j][ks] = *reinterpret_cast<const bf16x8*>(&TB[(wn * 64 + 32 * j + r) * LDS_BF + 16 * ks + 8 * hh]);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+      for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -261,15 +276,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
     if (more) {
       const int k0 = kbeg + (kt + 1) * BK;
-      stage_fix<A_KM, DROP>(sa, m0, g.M, k0, kend, tid, dc, g.M, g.K);
-      stage_fix<B_KM, false>(sb, n0, g.N, k0, kend, tid, nodrop, 0, 0);
+      stage_fix<BK, A_KM, DROP>(sa, m0, g.M, k0, kend, tid, dc, g.M, g.K);
+      stage_fix<BK, B_KM, false>(sb, n0, g.N, k0, kend, tid, nodrop, 0, 0);
       if (do_rowsum) add_rowsum();     // after the MFMAs: the loads have landed by now
       if (BF16) {
-        stage_store_bf16<A_KM>(sa, reinterpret_cast<unsigned short*>(tileA(buf ^ 1)), tid);
-        stage_store_bf16<B_KM>(sb, reinterpret_cast<unsigned short*>(tileB(buf ^ 1)), tid);
+        stage_store_bf16<BK, A_KM>(sa, reinterpret_cast<unsigned short*>(tileA(buf ^ 1)), tid);
+        stage_store_bf16<BK, B_KM>(sb, reinterpret_cast<unsigned short*>(tileB(buf ^ 1)), tid);
       } else {
-        stage_store_f32<A_KM>(sa, tileA(buf ^ 1), tid);
-        stage_store_f32<B_KM>(sb, tileB(buf ^ 1), tid);
+        stage_store_f32<BK, A_KM>(sa, tileA(buf ^ 1), tid);
+        stage_store_f32<BK, B_KM>(sb, tileB(buf ^ 1), tid);
       }
     }
     __syncthreads();
@@ -298,13 +313,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     // one 256-byte row segment, residual / saved-activation reads are float4 too.
     if (do_rowsum) __syncthreads();
     constexpr int ES = 68;
-    float* T = lds + wave * (64 * ES);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) T[(32 * i + crow(q, hh)) * ES + 32 * j + r] = acc[i][j][q];
+    constexpr int EB = (BK == 16) ? 2 : 4;     // row segments in flight per lane (register budget of the 4-waves/SIMD build)
+    static_assert(4 * 32 * ES <= 4 * TILE_FLOATS, "epilogue slabs must fit the staging buffers");
+    float* T = lds + wave * (32 * ES);
     const int c = (lane & 15) * 4;
     const int gcol = n0 + wn * 64 + c;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -312,47 +323,54 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const float* __restrict__ aux = g.res;      // residual or saved activation; must not alias C
     const bool need_aux = (aux != nullptr);
     const bool col_ok = gcol < g.N;
-    for (int it0 = 0; it0 < 16; it0 += 4) {
-      // batch of 4 row segments: issue every global read first, then compute, then store
-      float4 m[4], old[4], v[4];
-      bool ok[4];
-      size_t coff[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int rl = (it0 + u) * 4 + (lane >> 4);
-        const int grow = m0 + wm * 64 + rl;
-        ok[u] = col_ok && grow < g.M;
-        coff[u] = (size_t)(ok[u] ? grow : 0) * g.ldc + (col_ok ? gcol : 0);
-        v[u] = *reinterpret_cast<const float4*>(&T[rl * ES + c]);
-        m[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        old[u] = m[u];
-        if (need_aux) m[u] = *reinterpret_cast<const float4*>(aux + (size_t)(ok[u] ? grow : 0) * g.ldr + (col_ok ? gcol : 0));
-        if (accum) old[u] = *reinterpret_cast<const float4*>(g.C + coff[u]);
-      }
+    for (int i = 0; i < 2; ++i) {               // 32 rows per pass (LDS ops of one wave stay in order)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int grow = m0 + wm * 64 + (it0 + u) * 4 + (lane >> 4);
-        float o[4] = {v[u].x * g.alpha + bv.x, v[u].y * g.alpha + bv.y, v[u].z * g.alpha + bv.z, v[u].w * g.alpha + bv.w};
-        const float mm[4] = {m[u].x, m[u].y, m[u].z, m[u].w};
-        if (relu) {
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+        for (int q = 0; q < 16; ++q) T[crow(q, hh) * ES + 32 * j + r] = acc[i][j][q];
+      for (int it0 = 0; it0 < 8; it0 += EB) {
+        // batch of EB row segments: issue every global read first, then compute, then store
+        float4 m[EB], old[EB], v[EB];
+        bool ok[EB];
+        size_t coff[EB];
+#pragma unroll
+        for (int u = 0; u < EB; ++u) {
+          const int rl = (it0 + u) * 4 + (lane >> 4);
+          const int grow = m0 + wm * 64 + 32 * i + rl;
+          ok[u] = col_ok && grow < g.M;
+          coff[u] = (size_t)(ok[u] ? grow : 0) * g.ldc + (col_ok ? gcol : 0);
+          v[u] = *reinterpret_cast<const float4*>(&T[rl * ES + c]);
+          m[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          old[u] = m[u];
+          if (need_aux) m[u] = *reinterpret_cast<const float4*>(aux + (size_t)(ok[u] ? grow : 0) * g.ldr + (col_ok ? gcol : 0));
+          if (accum) old[u] = *reinterpret_cast<const float4*>(g.C + coff[u]);
         }
-        if (relumask) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = mm[e] > 0.f ? o[e] : 0.f;
-        } else {
-          if (de.on) {
-            const uint32_t base = (uint32_t)grow * (uint32_t)g.N + (uint32_t)gcol;
+        for (int u = 0; u < EB; ++u) {
+          const int grow = m0 + wm * 64 + 32 * i + (it0 + u) * 4 + (lane >> 4);
+          float o[4] = {v[u].x * g.alpha + bv.x, v[u].y * g.alpha + bv.y, v[u].z * g.alpha + bv.z, v[u].w * g.alpha + bv.w};
+          const float mm[4] = {m[u].x, m[u].y, m[u].z, m[u].w};
+          if (relu) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] *= drop_scale(de, base + e);
+            for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
           }
+          if (relumask) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] += mm[e];      // zero when there is no residual
+            for (int e = 0; e < 4; ++e) o[e] = mm[e] > 0.f ? o[e] : 0.f;
+          } else {
+            if (de.on) {
+              const uint32_t base = (uint32_t)grow * (uint32_t)g.N + (uint32_t)gcol;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] *= drop_scale(de, base + e);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += mm[e];      // zero when there is no residual
+          }
+          if (ok[u])
+            *reinterpret_cast<float4*>(g.C + coff[u]) =
+                make_float4(o[0] + old[u].x, o[1] + old[u].y, o[2] + old[u].z, o[3] + old[u].w);
         }
-        if (ok[u])
-          *reinterpret_cast<float4*>(g.C + coff[u]) =
-              make_float4(o[0] + old[u].x, o[1] + old[u].y, o[2] + old[u].z, o[3] + old[u].w);
       }
     }
     return;
@@ -387,20 +405,45 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
 }
 
-template <bool A_KM, bool B_KM, bool ALIGNED, bool BF16>
+template <int BK, bool A_KM, bool B_KM, bool ALIGNED, bool BF16>
 void launch2(const GemmArgs& g, dim3 grid, hipStream_t s, bool drop) {
-  if (drop) hipLaunchKernelGGL((gemm_kernel<A_KM, B_KM, ALIGNED, BF16, true>), grid, dim3(256), 0, s, g);
-  else hipLaunchKernelGGL((gemm_kernel<A_KM, B_KM, ALIGNED, BF16, false>), grid, dim3(256), 0, s, g);
+  if (drop) hipLaunchKernelGGL((gemm_kernel<BK, A_KM, B_KM, ALIGNED, BF16, true>), grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((gemm_kernel<BK, A_KM, B_KM, ALIGNED, BF16, false>), grid, dim3(256), 0, s, g);
 }
-template <bool A_KM, bool B_KM>
+template <int BK, bool A_KM, bool B_KM>
 void launch1(const GemmArgs& g, dim3 grid, hipStream_t s, bool aligned, bool bf16, bool drop) {
   if (aligned) {
-    if (bf16) launch2<A_KM, B_KM, true, true>(g, grid, s, drop);
-    else launch2<A_KM, B_KM, true, false>(g, grid, s, drop);
+    if (bf16) launch2<BK, A_KM, B_KM, true, true>(g, grid, s, drop);
+    else launch2<BK, A_KM, B_KM, true, false>(g, grid, s, drop);
   } else {
-    if (bf16) launch2<A_KM, B_KM, false, true>(g, grid, s, drop);
-    else launch2<A_KM, B_KM, false, false>(g, grid, s, drop);
+    if (bf16) launch2<BK, A_KM, B_KM, false, true>(g, grid, s, drop);
+    else launch2<BK, A_KM, B_KM, false, false>(g, grid, s, drop);
   }
+}
+template <int BK>
+void launch0(const GemmArgs& g, dim3 grid, hipStream_t s, bool a_km, bool b_km, bool aligned, bool bf16, bool drop) {
+  if (!a_km && !b_km) launch1<BK, false, false>(g, grid, s, aligned, bf16, drop);
+  else if (!a_km && b_km) launch1<BK, false, true>(g, grid, s, aligned, bf16, drop);
+  else if (a_km && b_km) launch1<BK, true, true>(g, grid, s, aligned, bf16, drop);
+  else launch1<BK, true, false>(g, grid, s, aligned, bf16, drop);
+}
+
+// Workgroups resident on the chip at once: 256 CUs x (LDS- and register-limited) 2 for BK = 32, 4 for BK = 16
+constexpr int SLOTS32 = 512, SLOTS16 = 1024;
+
+int forced_depth() {   // TVAE_GEMM_BK (16 | 32) overrides the choice below; read once
+  static int forced = [] { const char* e = getenv("TVAE_GEMM_BK"); return e ? atoi(e) : 0; }();
+  return (forced == 16 || forced == 32) ? forced : 0;
+}
+
+// BK = 16 runs three workgroups per CU and is a few percent faster when the grid fills whole
+// rounds of them; a grid that leaves the last round mostly empty is better off with BK = 32.
+int tile_depth(bool bf16, int tiles, bool splitk) {
+  if (int f = forced_depth()) return f;
+  if (bf16) return 32;
+  if (splitk) return 16;
+  auto eff = [](int t, int slots) { return (double)t / (double)(cdiv(t, slots) * slots); };
+  return eff(tiles, SLOTS16) * 1.03 >= eff(tiles, SLOTS32) ? 16 : 32;
 }
 
 }  // namespace
@@ -438,27 +481,28 @@ extern "C" int tvae_gemm(const float* A, int lda, const float* B, int ldb, float
       (!bias || aligned16(bias)) && (!residual || (ldr % 4 == 0 && aligned16(residual))))
     g.flags |= FLAG_VEC_EPILOGUE;
   TVAE_CHECK(!a_rowsum || a_km, TVAE_E_SHAPE, "tvae_gemm: a_rowsum needs a k-major A (wgrad form)");
+  const bool bf16 = dtype == TVAE_BF16;
   int tiles = cdiv(M, BM) * cdiv(N, BN);
+  const int BK = tile_depth(bf16, tiles, flags & TVAE_GEMM_SPLITK);
   int splits = 1;
   if (flags & TVAE_GEMM_SPLITK) {
-    int ktiles = cdiv(K, BK);
-    splits = 1024 / tiles;               // aim at ~4 workgroups per CU
-    if (splits > ktiles / 4) splits = ktiles / 4;   // keep >= 4 k-tiles per split
+    // one full round of resident workgroups, each with at least 256 of K: more splits only add
+    // atomic epilogues, fewer leave CUs idle
+    int ktiles = cdiv(K, 32);
+    splits = (BK == 16 ? SLOTS16 : SLOTS32) / tiles;
+    if (splits > ktiles / 8) splits = ktiles / 8;
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
-    g.k_per_split = cdiv(ktiles, splits) * BK;
+    g.k_per_split = cdiv(ktiles, splits) * 32;
     splits = cdiv(K, g.k_per_split);
   } else {
-    g.k_per_split = cdiv(K, BK) * BK;
+    g.k_per_split = cdiv(K, 32) * 32;
   }
   dim3 grid(tiles, 1, splits);
   const bool drop = (flags & TVAE_GEMM_A_DROPMASK) && rng && p_drop > 0.f;
   hipStream_t s = (hipStream_t)stream;
-  const bool bf16 = dtype == TVAE_BF16;
-  if (!a_km && !b_km) launch1<false, false>(g, grid, s, aligned, bf16, drop);
-  else if (!a_km && b_km) launch1<false, true>(g, grid, s, aligned, bf16, drop);
-  else if (a_km && b_km) launch1<true, true>(g, grid, s, aligned, bf16, drop);
-  else launch1<true, false>(g, grid, s, aligned, bf16, drop);
+  if (BK == 16) launch0<16>(g, grid, s, a_km, b_km, aligned, bf16, drop);
+  else launch0<32>(g, grid, s, a_km, b_km, aligned, bf16, drop);
   TVAE_LAUNCH_CHECK("tvae_gemm");
   return TVAE_OK;
 }

@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32")
     ap.add_argument("--batch", type=int, default=500)
     ap.add_argument("--chunks", type=int, default=5)
-    ap.add_argument("--decode-n", type=int, default=4096)
+    ap.add_argument("--decode-n", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     args = ap.parse_args()

@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
 }
 
 int check_common(const char* who, int B, int h, int Lq, int Lk, int dk, const int* lds, int nld, const void* const* ptrs,
-                 int nptr) {
+                 int nptr, bool dropout) {
   TVAE_CHECK(B > 0 && h > 0 && Lq >= 1 && Lk >= 1 && Lq <= 128 && Lk <= 128, TVAE_E_SHAPE,
              "%s: need 1 <= Lq,Lk <= 128 (got %d,%d), B=%d h=%d", who, Lq, Lk, B, h);
   TVAE_CHECK(dk == 32 || dk == 64, TVAE_E_SHAPE, "%s: dk=%d unsupported (32 or 64)", who, dk);
@@ -324,7 +324,8 @@ int check_common(const char* who, int B, int h, int Lq, int Lk, int dk, const in
     TVAE_CHECK(lds[i] % 4 == 0 && lds[i] >= h * dk, TVAE_E_SHAPE, "%s: leading dimension %d must be a multiple of 4 and >= h*dk", who, lds[i]);
   for (int i = 0; i < nptr; ++i)
     TVAE_CHECK(ptrs[i] && aligned16(ptrs[i]), TVAE_E_NULL, "%s: operand %d is null or not 16-byte aligned", who, i);
-  TVAE_CHECK((long)B * h * Lq * Lk < (1L << 32), TVAE_E_SHAPE, "%s: dropout index space exceeds 32 bits", who);
+  TVAE_CHECK(!dropout || (long)B * h * Lq * Lk < (1L << 32), TVAE_E_SHAPE, "%s: dropout index space exceeds 32 bits", who);
+  TVAE_CHECK((long)B * h < (1L << 31), TVAE_E_SHAPE, "%s: B*h exceeds the grid limit", who);
   return TVAE_OK;
 }
 
@@ -336,7 +337,7 @@ extern "C" int tvae_attn_fwd(const float* q, int ldq, const float* k, int ldk, c
                              float p_drop, int dtype, void* stream) {
   int lds[] = {ldq, ldk, ldv, ldo};
   const void* ptrs[] = {q, k, v, o};
-  int rc = check_common("tvae_attn_fwd", B, h, Lq, Lk, dk, lds, 4, ptrs, 4);
+  int rc = check_common("tvae_attn_fwd", B, h, Lq, Lk, dk, lds, 4, ptrs, 4, rng && p_drop > 0.f);
   if (rc) return rc;
   TVAE_CHECK(dtype == TVAE_F32 || dtype == TVAE_BF16, TVAE_E_DTYPE, "tvae_attn_fwd: dtype %d", dtype);
   AttnArgs a = {};
@@ -358,7 +359,7 @@ extern "C" int tvae_attn_bwd(const float* q, int ldq, const float* k, int ldk, c
                              const uint32_t* rng, uint32_t site, float p_drop, int dtype, void* stream) {
   int lds[] = {ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv};
   const void* ptrs[] = {q, k, v, o, d_o, dq, dk_, dv};
-  int rc = check_common("tvae_attn_bwd", B, h, Lq, Lk, dk, lds, 8, ptrs, 8);
+  int rc = check_common("tvae_attn_bwd", B, h, Lq, Lk, dk, lds, 8, ptrs, 8, rng && p_drop > 0.f);
   if (rc) return rc;
   TVAE_CHECK(lse && dsum, TVAE_E_NULL, "tvae_attn_bwd: lse / dsum workspace missing");
   TVAE_CHECK(dtype == TVAE_F32 || dtype == TVAE_BF16, TVAE_E_DTYPE, "tvae_attn_bwd: dtype %d", dtype);

@@ -462,7 +462,7 @@ extern "C" int tvae_gemm(const float* A, int lda, const float* B, int ldb, float
              "tvae_gemm: leading dimension too small (lda %d ldb %d ldc %d, N %d)", lda, ldb, ldc, N);
   TVAE_CHECK(!((flags & 64) && !residual), TVAE_E_NULL, "tvae_gemm: RELUMASK needs the saved activation");
   TVAE_CHECK(!residual || ldr >= N, TVAE_E_SHAPE, "tvae_gemm: ldr %d < N %d", ldr, N);
-  TVAE_CHECK((long)M * N < (1L << 32) && (long)M * K < (1L << 32), TVAE_E_SHAPE,
+  TVAE_CHECK(!(rng && p_drop > 0.f) || ((long)M * N < (1L << 32) && (long)M * K < (1L << 32)), TVAE_E_SHAPE,
              "tvae_gemm: dropout index space exceeds 32 bits");
   if (flags & TVAE_GEMM_SPLITK)
     TVAE_CHECK(!(flags & (TVAE_GEMM_RELU | 64)) && !residual, TVAE_E_SHAPE,

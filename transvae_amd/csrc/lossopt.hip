@@ -208,50 +208,89 @@ __global__ __launch_bounds__(256) void adam_kernel(void* const* ptrs, const int6
 // ------------------------------------------------------------------------------- decode helpers
 constexpr float MASK_FILL = -1e9f;
 
-// one wave per (molecule, head): q (dk) against n_keys cached rows
+// One wave per (molecule, head): q (dk) against n_keys cached rows.  HBM-bound (the K/V rows are
+// read once per step), so the point is to read them in whole cache lines and to read nothing that
+// cannot matter:
+//   scores: 4 lanes share a key row (64 B per lane group and instruction, 16 keys per instruction),
+//           the partial dot products meet in two DPP adds;
+//   masked keys are not read at all: their score is the -1e9 fill, and unless EVERY key of the row
+//           is masked exp(-1e9 - max) is exactly 0 in fp32, so their V rows are skipped too (an
+//           all-masked row attends uniformly to all n_keys, as in the reference, and reads them);
+//   P.V: dk/4 lanes cover one V row with float4 loads, 64/(dk/4) rows in flight per instruction.
+template <int DK>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ kc,
                                                           const float* __restrict__ vc, int ldc, int Lcache,
                                                           float* __restrict__ o, int ldo, const uint8_t* __restrict__ key_mask,
-                                                          int ld_mask, int n_keys, int n, int h, int dk, float scale) {
+                                                          int ld_mask, int n_keys, int n, int h, float scale) {
+  constexpr int NF4 = DK / 16;            // float4 per lane in the score phase
+  constexpr int LPR = DK / 4;             // lanes per V row
+  constexpr int KG = 64 / LPR;            // V rows per wave instruction
   __shared__ float ps[4][128];
-  __shared__ float qs[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pair = blockIdx.x * 4 + wave;
   const bool active = pair < n * h;
   const int b = active ? pair / h : 0, head = active ? pair % h : 0;
-  if (lane < dk) qs[wave][lane] = q[(size_t)b * ldq + head * dk + lane];
-  __syncthreads();
-  float sc[2];
+  const int part = lane & 3, kl = lane >> 2;
+  float4 qr[NF4];
+#pragma unroll
+  for (int it = 0; it < NF4; ++it)
+    qr[it] = *reinterpret_cast<const float4*>(q + (size_t)b * ldq + head * DK + 16 * it + 4 * part);
+  const float* kbase = kc + (size_t)b * Lcache * ldc + head * DK + 4 * part;
+  const uint8_t* mrow = key_mask ? key_mask + (size_t)b * ld_mask : nullptr;
+  float sc[8];
   float mx = -INFINITY;
 #pragma unroll
-  for (int j2 = 0; j2 < 2; ++j2) {
-    int j = lane + 64 * j2;
+  for (int g = 0; g < 8; ++g) {
+    const int key = 16 * g + kl;
     float s = -INFINITY;
-    if (j < n_keys) {
-      const float* kr = kc + ((size_t)b * Lcache + j) * ldc + head * dk;
+    if (16 * g < n_keys) {                          // wave-uniform
+      const bool valid = key < n_keys;
+      const bool m = valid && (mrow ? mrow[key] != 0 : true);
       float acc = 0.f;
-      for (int c = 0; c < dk; c += 4) {
-        float4 kv = *reinterpret_cast<const float4*>(kr + c);
-        acc += kv.x * qs[wave][c] + kv.y * qs[wave][c + 1] + kv.z * qs[wave][c + 2] + kv.w * qs[wave][c + 3];
+      if (m) {
+        const float* kr = kbase + (size_t)key * ldc;
+#pragma unroll
+        for (int it = 0; it < NF4; ++it) {
+          float4 kv = *reinterpret_cast<const float4*>(kr + 16 * it);
+          acc += kv.x * qr[it].x + kv.y * qr[it].y + kv.z * qr[it].z + kv.w * qr[it].w;
+        }
       }
-      bool m = key_mask ? key_mask[(size_t)b * ld_mask + j] != 0 : true;
-      s = m ? acc * scale : MASK_FILL;
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      if (valid) s = m ? acc * scale : MASK_FILL;
     }
-    sc[j2] = s;
+    sc[g] = s;
     mx = fmaxf(mx, s);
   }
   mx = wave_max(mx);
-  float e0 = expf(sc[0] - mx), e1 = expf(sc[1] - mx);
-  float inv = 1.f / wave_sum(e0 + e1);
-  ps[wave][lane] = e0 * inv;
-  ps[wave][lane + 64] = e1 * inv;
-  __syncthreads();
-  if (active && lane < dk) {
-    const float* vr = vc + (size_t)b * Lcache * ldc + head * dk + lane;
-    float acc = 0.f;
-    for (int j = 0; j < n_keys; ++j) acc += ps[wave][j] * vr[(size_t)j * ldc];
-    o[(size_t)b * ldo + head * dk + lane] = acc;
+  float loc = 0.f;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    sc[g] = expf(sc[g] - mx);                       // exp(-inf) = 0 for keys past n_keys
+    loc += sc[g];
   }
+  const float inv = 1.f / wave_sum(part == 0 ? loc : 0.f);
+  if (part == 0) {
+#pragma unroll
+    for (int g = 0; g < 8; ++g) ps[wave][16 * g + kl] = sc[g] * inv;
+  }
+  __syncthreads();
+  const int c4 = lane % LPR, kg = lane / LPR;
+  const float* vbase = vc + (size_t)b * Lcache * ldc + head * DK + 4 * c4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j = kg; j < n_keys; j += KG) {
+    const float p = ps[wave][j];
+    if (p != 0.f) {
+      const float4 v = *reinterpret_cast<const float4*>(vbase + (size_t)j * ldc);
+      acc.x += p * v.x; acc.y += p * v.y; acc.z += p * v.z; acc.w += p * v.w;
+    }
+  }
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+    acc.x += __shfl_xor(acc.x, off, 64); acc.y += __shfl_xor(acc.y, off, 64);
+    acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
+  }
+  if (active && kg == 0) *reinterpret_cast<float4*>(o + (size_t)b * ldo + head * DK + 4 * c4) = acc;
 }
 
 __global__ void argmax_kernel(const float* __restrict__ logits, int ldl, int n_cls, int64_t* ids, int ld_ids, int col,
@@ -343,11 +382,16 @@ extern "C" int tvae_decode_attn(const float* q, int ldq, const float* kc, const 
                                 float scale, void* stream) {
   TVAE_CHECK(q && kc && vc && o, TVAE_E_NULL, "tvae_decode_attn: null pointer");
   TVAE_CHECK(n > 0 && h > 0 && n_keys >= 1 && n_keys <= 128 && n_keys <= Lcache && (dk == 32 || dk == 64) &&
-                 ldc % 4 == 0 && aligned16(kc) && aligned16(vc),
-             TVAE_E_SHAPE, "tvae_decode_attn: need 1<=n_keys<=128, dk in {32,64}, 16-byte aligned caches (n_keys=%d dk=%d)",
+                 ldc % 4 == 0 && ldq % 4 == 0 && ldo % 4 == 0 && aligned16(kc) && aligned16(vc) && aligned16(q) && aligned16(o),
+             TVAE_E_SHAPE, "tvae_decode_attn: need 1<=n_keys<=128, dk in {32,64}, 16-byte aligned rows (n_keys=%d dk=%d)",
              n_keys, dk);
-  hipLaunchKernelGGL(decode_attn_kernel, dim3(cdiv((long)n * h, 4)), dim3(256), 0, (hipStream_t)stream, q, ldq, kc, vc,
-                     ldc, Lcache, o, ldo, key_mask, ld_mask, n_keys, n, h, dk, scale);
+  dim3 grid(cdiv((long)n * h, 4));
+  if (dk == 64)
+    hipLaunchKernelGGL(decode_attn_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, q, ldq, kc, vc, ldc, Lcache, o,
+                       ldo, key_mask, ld_mask, n_keys, n, h, scale);
+  else
+    hipLaunchKernelGGL(decode_attn_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, q, ldq, kc, vc, ldc, Lcache, o,
+                       ldo, key_mask, ld_mask, n_keys, n, h, scale);
   TVAE_LAUNCH_CHECK("tvae_decode_attn");
   return TVAE_OK;
 }

@@ -197,8 +197,17 @@ def main():
         tg = time_gemm(M, N, K, args.dtype)
         flops = 2.0 * M * N * K
         ach = flops / tg / 1e12
+        # HBM bytes per launch of this kernel and shape, from separate rocprofv3 --pmc passes
+        # (tools/pmc_traffic.sh -> profiles/r1_gemm_pmc.json); None when no such measurement exists
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r1_gemm_pmc.json")
+        if args.dtype == "fp32" and os.path.exists(pmc):
+            rec = json.load(open(pmc))
+            if rec.get("shape") == [M, N, K]:
+                traffic = rec["traffic_bytes_per_launch"]
         out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                           "frac": ach / PEAK_TFLOPS[args.dtype], "traffic": None,
+                           "frac": ach / PEAK_TFLOPS[args.dtype], "traffic": traffic,
+                           "algorithmic_bytes": 4.0 * (M * K + N * K + N + M * N),
                            "kernel": "gemm_kernel (x[%d,%d] @ W[%d,%d]^T + bias, ReLU)" % (M, K, N, K),
                            "launch_us": tg * 1e6, "flop_per_launch": flops}
         if not args.no_cpu_baseline and world == 1:

@@ -12,7 +12,7 @@
  *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless
  *     a parameter is documented as host;
  *   - every function is asynchronous on `stream` (a hipStream_t passed as void*), never
- *     allocates and never synchronises (the only exception is tvae_noalloc_* set-up);
+ *     allocates and never synchronises;
  *   - return 0 on success, a negative TVAE_E_* code otherwise; tvae_last_error() returns a
  *     thread-local message for the last failure;
  *   - matrices are row-major fp32; "ld" is the row stride in elements;
@@ -22,6 +22,8 @@
  *   - dropout: `rng` points at two device uint32 {seed, step}; `site` names the call site;
  *     the keep-mask is a counter-based hash of (seed, step, site, element index), so the
  *     backward kernels regenerate it instead of storing it.  p == 0 or rng == NULL: off.
+ *     p is quantised to 1/65536 (0.1 -> 6554/65536) and kept elements are scaled by exactly
+ *     1 / P(keep).
  */
 #ifndef TVAE_KERNELS_H
 #define TVAE_KERNELS_H
@@ -104,7 +106,9 @@ int tvae_attn_fwd(const float* q, int ldq, const float* k, int ldk, const float*
                   int B, int h, int Lq, int Lk, int dk, float scale,
                   const uint32_t* rng, uint32_t site, float p_drop, int dtype, void* stream);
 /* Backward of the above.  dq/dk/dv use the same addressing as q/k/v (may be strided views);
- * every element of the addressed head slices is written.  dsum (B, h, Lq) is workspace. */
+ * every element of the addressed head slices is written.  dsum is workspace, 16-byte aligned, of
+ * R4 + 4*R floats with R = B*h*Lq and R4 = R rounded up to a multiple of 4: the per-row sum_j P_j dP_j
+ * followed by four 32-bit dropout keep words per row (written by the dQ kernel, read by the dK/dV kernel). */
 int tvae_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                   const float* o, int ldo, const float* d_o, int lddo, const float* lse,
                   float* dq, int lddq, float* dk_, int lddk, float* dv, int lddv, float* dsum,

@@ -1,0 +1,10 @@
+#!/bin/bash
+# HBM traffic of the roofline GEMM from the L2 memory-side counters: two separate rocprofv3 --pmc
+# passes (FETCH_SIZE and WRITE_SIZE cannot share a pass, MI355X_MICROARCH.md "rocprofv3 PMC slots").
+# Run on the GPU box from the repo root:  bash tools/pmc_traffic.sh  -> gpurun_out/pmc_{fetch,write}/
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp || exit 1
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$R/gpurun_out/pmc_fetch" -- python3 "$R/tools/pmc_gemm.py" > "$R/gpurun_out/pmc_fetch.log" 2>&1 || exit 1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$R/gpurun_out/pmc_write" -- python3 "$R/tools/pmc_gemm.py" > "$R/gpurun_out/pmc_write.log" 2>&1 || exit 1
+cd "$R" && python3 tools/pmc_summarise.py

@@ -94,11 +94,36 @@ __device__ inline void store_rowmajor(float* __restrict__ rowp, const floatx16 (
     }
 }
 
-__device__ inline bool mask_bit(const AttnArgs& a, int b, int qi, int key, const uint8_t* kmask_s) {
-  bool m = kmask_s[key] != 0;
-  if (a.causal) m = m && (key <= qi);
-  if (a.full_mask) m = m && (a.full_mask[((size_t)b * a.Lq + qi) * a.Lk + key] != 0);
+// Mask of one (query, 32-key tile) as a 32-bit word, bit j = key 32t + j may be attended.
+// key_bits[t] holds the (B, Lk) key mask of this molecule (bits past Lk are 0).
+__device__ inline uint32_t tile_mask(const AttnArgs& a, int b, int qi, int t, const uint32_t* key_bits) {
+  uint32_t m = key_bits[t];
+  if (a.causal) {
+    const int last = qi - 32 * t;                         // keys 32t .. 32t+last are visible
+    m &= last < 0 ? 0U : (last >= 31 ? 0xFFFFFFFFU : ((2U << last) - 1U));
+  }
+  if (a.full_mask) {
+    const uint8_t* fm = a.full_mask + ((size_t)b * a.Lq + qi) * a.Lk + 32 * t;
+    uint32_t w = 0;
+    for (int j = 0; j < 32 && 32 * t + j < a.Lk; ++j) w |= (fm[j] != 0 ? 1U : 0U) << j;
+    m &= w;
+  }
   return m;
+}
+
+// key-mask words of molecule b into LDS (bit j of word t = key 32t+j unmasked and < Lk): wave 0 ballots
+__device__ inline void load_key_bits(uint32_t* key_bits, const AttnArgs& a, int b, int tid) {
+  if (tid < 128) {
+    const bool m = (tid < a.Lk) && (a.key_mask ? a.key_mask[(size_t)b * a.Lk + tid] != 0 : true);
+    const unsigned long long bal = __ballot(m);
+    if ((tid & 63) == 0) { key_bits[(tid >> 6) * 2] = (uint32_t)bal; key_bits[(tid >> 6) * 2 + 1] = (uint32_t)(bal >> 32); }
+  }
+}
+
+// Dropout on the attention weights is indexed (row, key) with a row pitch of 128, so the four keys
+// 8g + 4hh + {0..3} a lane holds in accumulator registers 4g..4g+3 are one hash group.
+__device__ inline uint32_t drop_group(size_t prow, int t, int g, int hh) {
+  return (uint32_t)(prow * 32 + 8 * t + 2 * g + hh);
 }
 
 // ------------------------------------------------------------------------------- forward
@@ -107,17 +132,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   constexpr int LS = DK + 4, HALF = DK / 2, NU = DK / 32;
   __shared__ __attribute__((aligned(16))) float Ks[128 * LS];
   __shared__ __attribute__((aligned(16))) float Vs[128 * LS];
-  __shared__ uint8_t kmask_s[128];
+  __shared__ uint32_t key_bits[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const int b = blockIdx.x / a.h, head = blockIdx.x % a.h;
   const int qi = 32 * wave + r;
   const bool qvalid = qi < a.Lq;
+  const int qs = qvalid ? qi : 0;
 
   load_tile_to_lds<DK>(Ks, a.k + (size_t)b * a.Lk * a.ldk + head * DK, a.ldk, a.Lk, tid);
   load_tile_to_lds<DK>(Vs, a.v + (size_t)b * a.Lk * a.ldv + head * DK, a.ldv, a.Lk, tid);
-  if (tid < 128) kmask_s[tid] = (tid < a.Lk) ? (a.key_mask ? a.key_mask[(size_t)b * a.Lk + tid] : 1) : 0;
+  load_key_bits(key_bits, a, b, tid);
   float qreg[HALF];
-  load_row_half<HALF>(qreg, a.q + ((size_t)b * a.Lq + (qvalid ? qi : 0)) * a.ldq + head * DK + hh * HALF, qvalid);
+  load_row_half<HALF>(qreg, a.q + ((size_t)b * a.Lq + qs) * a.ldq + head * DK + hh * HALF, qvalid);
   __syncthreads();
 
   DropCfg dc = drop_cfg(a.rng, a.site, a.p);
@@ -126,12 +152,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     st[t] = mma_rows_x_reg<DK>(Ks, 32 * t + r, hh, qreg);
+    const uint32_t mw = tile_mask(a, b, qs, t, key_bits) >> (4 * hh);
+    const int nk = a.Lk - 32 * t - 4 * hh;                 // keys of this tile with in-lane offset < nk exist
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      int key = 32 * t + crow(i, hh);
+      const int off = crow(i, 0);                          // compile-time
       float s;
-      if (key >= a.Lk) s = -INFINITY;
-      else s = mask_bit(a, b, qvalid ? qi : 0, key, kmask_s) ? st[t][i] * a.scale : MASK_FILL;
+      if (off >= nk) s = -INFINITY;
+      else s = ((mw >> off) & 1U) ? st[t][i] * a.scale : MASK_FILL;
       st[t][i] = s;
       mx = fmaxf(mx, s);
     }
@@ -163,12 +191,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      int key = 32 * t + crow(i, hh);
-      float p = st[t][i] * inv;
-      if (a.p_out && qvalid && key < a.Lk) a.p_out[prow * a.Lk + key] = p;
-      if (dc.on) p *= drop_scale(dc, (uint32_t)(prow * a.Lk + key));
-      st[t][i] = p;
+    for (int g = 0; g < 4; ++g) {
+      uint32_t keep = 0xFU;
+      if (dc.on) keep = drop_keep4(dc, drop_group(prow, t, g, hh));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * g + e;
+        float p = st[t][i] * inv;
+        if (a.p_out) {
+          const int key = 32 * t + crow(i, hh);
+          if (qvalid && key < a.Lk) a.p_out[prow * a.Lk + key] = p;
+        }
+        if (dc.on) p = ((keep >> e) & 1U) ? p * dc.scale : 0.f;
+        st[t][i] = p;
+      }
     }
     mma_cols_x_acc<DK>(oacc, Vs, 32 * t, hh, r, st[t]);
   }
@@ -176,19 +212,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------- backward: dQ
-// Same orientation as the forward (query on the lane).  Two passes over the key tiles:
-//   pass 1: P (kept in registers) and dP -> dsum = sum_j P_j dP_j / sum_j P_j
-//   pass 2: dP again -> dS = P (dP - dsum) -> dQ^T += K^T dS^T
+// Same orientation as the forward (query on the lane), ONE pass: P and dP of the whole row stay in
+// registers (128 of them), dsum = sum_j P_j dP_j / sum_j P_j, dS = P (dP - dsum), dQ^T += K^T dS^T.
 // dsum is formed from the SAME P and dP values that enter dS, so sum_j dS_j vanishes to rounding.
 // (The flash-attention shortcut dsum = rowsum(dO * O) is the same number mathematically, but its
 // rounding error is common to every key of the row and gets multiplied by the MEAN key; with the
 // near-uniform source attention of this model that error was 3-4x the reference's own.)
+// Also leaves, for the dK/dV kernel: dsum per row and the dropout keep flags of the row as four
+// 32-bit words (that kernel holds the key on the lane and would need one hash per element).
 template <int DK>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+void attn_bwd_dq_kernel(AttnArgs a) {
   constexpr int LS = DK + 4, HALF = DK / 2, NU = DK / 32;
   __shared__ __attribute__((aligned(16))) float Ks[128 * LS];
   __shared__ __attribute__((aligned(16))) float Vs[128 * LS];
-  __shared__ uint8_t kmask_s[128];
+  __shared__ uint32_t key_bits[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const int b = blockIdx.x / a.h, head = blockIdx.x % a.h;
   const int qi = 32 * wave + r;
@@ -197,69 +235,95 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 
   load_tile_to_lds<DK>(Ks, a.k + (size_t)b * a.Lk * a.ldk + head * DK, a.ldk, a.Lk, tid);
   load_tile_to_lds<DK>(Vs, a.v + (size_t)b * a.Lk * a.ldv + head * DK, a.ldv, a.Lk, tid);
-  if (tid < 128) kmask_s[tid] = (tid < a.Lk) ? (a.key_mask ? a.key_mask[(size_t)b * a.Lk + tid] : 1) : 0;
-  float qreg[HALF], doreg[HALF];
-  load_row_half<HALF>(qreg, a.q + ((size_t)b * a.Lq + qs) * a.ldq + head * DK + hh * HALF, qvalid);
-  load_row_half<HALF>(doreg, a.d_o + ((size_t)b * a.Lq + qs) * a.lddo + head * DK + hh * HALF, qvalid);
+  load_key_bits(key_bits, a, b, tid);
   const size_t prow = ((size_t)(b * a.h + head) * a.Lq + qi);
   const float row_mx = qvalid ? a.lse_in[2 * prow] : 0.f;
   const float row_ls = qvalid ? a.lse_in[2 * prow + 1] : 0.f;
-  __syncthreads();
-
   DropCfg dc = drop_cfg(a.rng, a.site, a.p);
-  floatx16 pt[4];
+  floatx16 pt[4], dpt[4];
+  uint32_t mwt[4], kwt[4];
+  {
+    float qreg[HALF], doreg[HALF];
+    load_row_half<HALF>(qreg, a.q + ((size_t)b * a.Lq + qs) * a.ldq + head * DK + hh * HALF, qvalid);
+    load_row_half<HALF>(doreg, a.d_o + ((size_t)b * a.Lq + qs) * a.lddo + head * DK + hh * HALF, qvalid);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      pt[t] = mma_rows_x_reg<DK>(Ks, 32 * t + r, hh, qreg);
+      dpt[t] = mma_rows_x_reg<DK>(Vs, 32 * t + r, hh, doreg);
+    }
+  }
   float dsum = 0.f, psum = 0.f;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    floatx16 s = mma_rows_x_reg<DK>(Ks, 32 * t + r, hh, qreg);
-    floatx16 dp = mma_rows_x_reg<DK>(Vs, 32 * t + r, hh, doreg);
+    const uint32_t mw = tile_mask(a, b, qs, t, key_bits) >> (4 * hh);
+    mwt[t] = mw;
+    const int nk = qvalid ? a.Lk - 32 * t - 4 * hh : 0;
+    uint32_t kw = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      int key = 32 * t + crow(i, hh);
-      float p = 0.f;
-      if (key < a.Lk && qvalid) {
-        float sc = mask_bit(a, b, qi, key, kmask_s) ? s[i] * a.scale : MASK_FILL;
-        p = expf(sc - row_mx) * row_ls;
-        psum += p;
-        dsum += p * (dp[i] * drop_scale(dc, (uint32_t)(prow * a.Lk + key)));
+    for (int g = 0; g < 4; ++g) {
+      uint32_t keep = 0xFU;
+      if (dc.on) keep = drop_keep4(dc, drop_group(prow, t, g, hh));
+      kw |= keep << (8 * g);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * g + e, off = crow(i, 0);
+        float p = 0.f, dp = 0.f;
+        if (off < nk) {
+          const float sc = ((mw >> off) & 1U) ? pt[t][i] * a.scale : MASK_FILL;
+          p = expf(sc - row_mx) * row_ls;
+          dp = ((keep >> e) & 1U) ? dpt[t][i] * dc.scale : 0.f;
+          psum += p;
+          dsum += p * dp;
+        }
+        pt[t][i] = p;
+        dpt[t][i] = dp;
       }
-      pt[t][i] = p;
     }
+    kwt[t] = kw << (4 * hh);        // bit (8g + 4hh + e) of word t = keep flag of key 32t + 8g + 4hh + e
   }
   dsum += __shfl_xor(dsum, 32, 64);
   psum += __shfl_xor(psum, 32, 64);
   // normalise by the ACTUAL sum of the P values used below, so that sum_j dS_j = 0 to rounding
   dsum = qvalid ? dsum / psum : 0.f;
-  if (qvalid && hh == 0) a.dsum[prow] = dsum;
+  const size_t rows_pad = ((size_t)a.B * a.h * a.Lq + 3) & ~(size_t)3;
+  if (qvalid) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) kwt[t] |= __shfl_xor(kwt[t], 32, 64);
+    if (hh == 0) {
+      a.dsum[prow] = dsum;
+      uint4 w = make_uint4(kwt[0], kwt[1], kwt[2], kwt[3]);
+      *reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(a.dsum) + rows_pad + 4 * prow) = w;
+    }
+  }
 
   floatx16 dqacc[NU];
 #pragma unroll
   for (int u = 0; u < NU; ++u) dqacc[u] = zero16();
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    floatx16 dp = mma_rows_x_reg<DK>(Vs, 32 * t + r, hh, doreg);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      int key = 32 * t + crow(i, hh);
-      float ds = 0.f;
-      if (key < a.Lk && qvalid && mask_bit(a, b, qi, key, kmask_s))
-        ds = pt[t][i] * (dp[i] * drop_scale(dc, (uint32_t)(prow * a.Lk + key)) - dsum) * a.scale;
-      dp[i] = ds;
+      // masked entries were REPLACED by the fill value in the forward: no gradient through them
+      const float ds = ((mwt[t] >> crow(i, 0)) & 1U) ? pt[t][i] * (dpt[t][i] - dsum) * a.scale : 0.f;
+      dpt[t][i] = ds;
     }
-    mma_cols_x_acc<DK>(dqacc, Ks, 32 * t, hh, r, dp);
+    mma_cols_x_acc<DK>(dqacc, Ks, 32 * t, hh, r, dpt[t]);
   }
   if (qvalid) store_rowmajor<DK>(a.dq + ((size_t)b * a.Lq + qi) * a.lddq + head * DK, dqacc, hh);
 }
 
 // ------------------------------------------------------------------------------- backward: dK, dV
 // Key on the lane: S = Q K^T and dP = dO V^T come out as [query regs][key lanes], which is the
-// B operand of dV^T = dO^T P and dK^T = Q^T dS directly.
+// B operand of dV^T = dO^T P and dK^T = Q^T dS directly.  Row statistics, dsum and the dropout keep
+// words come from the dQ kernel's workspace (one LDS broadcast read per query).
 template <int DK>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
   constexpr int LS = DK + 4, HALF = DK / 2, NU = DK / 32;
   __shared__ __attribute__((aligned(16))) float Qs[128 * LS];
   __shared__ __attribute__((aligned(16))) float Gs[128 * LS];   // dO
   __shared__ float mx_s[128], ls_s[128], dsum_s[128];
+  __shared__ uint32_t keep_s[128][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const int b = blockIdx.x / a.h, head = blockIdx.x % a.h;
   const int key = 32 * wave + r;
@@ -268,11 +332,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
 
   load_tile_to_lds<DK>(Qs, a.q + (size_t)b * a.Lq * a.ldq + head * DK, a.ldq, a.Lq, tid);
   load_tile_to_lds<DK>(Gs, a.d_o + (size_t)b * a.Lq * a.lddo + head * DK, a.lddo, a.Lq, tid);
+  DropCfg dc = drop_cfg(a.rng, a.site, a.p);
   if (tid < 128) {
     size_t prow = ((size_t)(b * a.h + head) * a.Lq + tid);
-    mx_s[tid] = tid < a.Lq ? a.lse_in[2 * prow] : 0.f;
-    ls_s[tid] = tid < a.Lq ? a.lse_in[2 * prow + 1] : 0.f;
-    dsum_s[tid] = tid < a.Lq ? a.dsum[prow] : 0.f;
+    const bool ok = tid < a.Lq;
+    mx_s[tid] = ok ? a.lse_in[2 * prow] : 0.f;
+    ls_s[tid] = ok ? a.lse_in[2 * prow + 1] : 0.f;
+    dsum_s[tid] = ok ? a.dsum[prow] : 0.f;
+    const size_t rows_pad = ((size_t)a.B * a.h * a.Lq + 3) & ~(size_t)3;
+    uint4 w = make_uint4(~0U, ~0U, ~0U, ~0U);
+    if (ok && dc.on) w = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(a.dsum) + rows_pad + 4 * prow);
+    *reinterpret_cast<uint4*>(&keep_s[tid][0]) = w;
   }
   float kreg[HALF], vreg[HALF];
   load_row_half<HALF>(kreg, a.k + ((size_t)b * a.Lk + ks) * a.ldk + head * DK + hh * HALF, kvalid);
@@ -280,7 +350,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
   const bool kbit = kvalid && (a.key_mask ? a.key_mask[(size_t)b * a.Lk + key] != 0 : true);
   __syncthreads();
 
-  DropCfg dc = drop_cfg(a.rng, a.site, a.p);
   floatx16 dkacc[NU], dvacc[NU];
 #pragma unroll
   for (int u = 0; u < NU; ++u) { dkacc[u] = zero16(); dvacc[u] = zero16(); }
@@ -298,8 +367,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
         if (a.full_mask) m = m && (a.full_mask[((size_t)b * a.Lq + qi) * a.Lk + key] != 0);
         float sc = m ? s[i] * a.scale : MASK_FILL;
         float p = expf(sc - mx_s[qi]) * ls_s[qi];
-        size_t prow = ((size_t)(b * a.h + head) * a.Lq + qi);
-        float ksc = drop_scale(dc, (uint32_t)(prow * a.Lk + key));
+        float ksc = ((keep_s[qi][wave] >> r) & 1U) ? dc.scale : 0.f;
         pt = p * ksc;
         if (m) ds = p * (dp[i] * ksc - dsum_s[qi]) * a.scale;
       }
@@ -361,7 +429,7 @@ extern "C" int tvae_attn_bwd(const float* q, int ldq, const float* k, int ldk, c
   const void* ptrs[] = {q, k, v, o, d_o, dq, dk_, dv};
   int rc = check_common("tvae_attn_bwd", B, h, Lq, Lk, dk, lds, 8, ptrs, 8, rng && p_drop > 0.f);
   if (rc) return rc;
-  TVAE_CHECK(lse && dsum, TVAE_E_NULL, "tvae_attn_bwd: lse / dsum workspace missing");
+  TVAE_CHECK(lse && dsum && aligned16(dsum), TVAE_E_NULL, "tvae_attn_bwd: lse / dsum workspace missing or not 16-byte aligned");
   TVAE_CHECK(dtype == TVAE_F32 || dtype == TVAE_BF16, TVAE_E_DTYPE, "tvae_attn_bwd: dtype %d", dtype);
   AttnArgs a = {};
   a.q = q; a.k = k; a.v = v; a.o = o; a.d_o = d_o; a.lse_in = lse;

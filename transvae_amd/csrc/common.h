@@ -33,17 +33,19 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // ---- counter-based dropout -------------------------------------------------------------
-// keep(idx) = mix(idx ^ key) >= p * 2^32 with key = mix(seed, step, site).  The same
-// (rng, site, idx) always gives the same decision, which is what lets the backward kernels
-// regenerate the mask.  mix = "lowbias32" integer finaliser.
+// Decisions come in GROUPS of four consecutive element indices: group g = idx >> 2 hashes to two
+// 32-bit words (5 integer multiplies for 4 elements -- v_mul_lo_u32 is quarter rate, and the hash
+// sits inside GEMM staging and the attention softmax), element idx & 3 takes a 16-bit field and is
+// kept iff field >= p * 65536.  The same (rng, site, idx) always gives the same decision, which is
+// what lets the backward kernels regenerate the mask instead of storing it.  mix = "lowbias32".
 __host__ __device__ inline uint32_t tvae_mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
 struct DropCfg {
   uint32_t key;
-  uint32_t thresh;  // keep iff hash >= thresh
-  float scale;      // 1/(1-p)
+  uint32_t thresh;  // keep iff 16-bit field >= thresh
+  float scale;      // 1 / P(keep)
   bool on;
 };
 __device__ inline DropCfg drop_cfg(const uint32_t* rng, uint32_t site, float p) {
@@ -53,15 +55,45 @@ __device__ inline DropCfg drop_cfg(const uint32_t* rng, uint32_t site, float p) 
   if (c.on) {
     uint32_t seed = rng[0], step = rng[1];
     c.key = tvae_mix32(seed ^ tvae_mix32(step * 0x9E3779B1U + site * 0x85EBCA6BU + 0x1234567U));
-    double t = (double)p * 4294967296.0;
-    c.thresh = t >= 4294967295.0 ? 0xFFFFFFFFU : (uint32_t)t;
-    c.scale = 1.f / (1.f - p);
+    float t = p * 65536.f + 0.5f;
+    c.thresh = t >= 65535.f ? 65535U : (uint32_t)t;
+    c.scale = 65536.f / (float)(65536U - c.thresh);     // exactly 1 / P(keep): the estimator stays unbiased
   }
   return c;
 }
+__device__ inline void drop_words(const DropCfg& c, uint32_t group, uint32_t& h1, uint32_t& h2) {
+  h1 = tvae_mix32(group * 0x9E3779B1U ^ c.key);
+  h2 = tvae_mix32(h1 ^ 0x3C6EF372U);
+}
+// keep flags of the four elements of `group` as bits 0..3
+__device__ inline uint32_t drop_keep4(const DropCfg& c, uint32_t group) {
+  uint32_t h1, h2;
+  drop_words(c, group, h1, h2);
+  return ((h1 & 0xFFFFU) >= c.thresh ? 1U : 0U) | ((h1 >> 16) >= c.thresh ? 2U : 0U) |
+         ((h2 & 0xFFFFU) >= c.thresh ? 4U : 0U) | ((h2 >> 16) >= c.thresh ? 8U : 0U);
+}
 __device__ inline float drop_scale(const DropCfg& c, uint32_t idx) {
   if (!c.on) return 1.f;
-  return tvae_mix32(idx * 0x9E3779B1U ^ c.key) >= c.thresh ? c.scale : 0.f;
+  uint32_t h1, h2;
+  drop_words(c, idx >> 2, h1, h2);
+  const uint32_t w = (idx & 2U) ? h2 : h1;
+  const uint32_t f = (idx & 1U) ? (w >> 16) : (w & 0xFFFFU);
+  return f >= c.thresh ? c.scale : 0.f;
+}
+// keep-scales of elements base .. base+3 (one hash when base is a multiple of 4)
+__device__ inline void drop_scale4(const DropCfg& c, uint32_t base, float (&s)[4]) {
+  if (!c.on) { s[0] = s[1] = s[2] = s[3] = 1.f; return; }
+  if ((base & 3U) == 0U) {
+    uint32_t h1, h2;
+    drop_words(c, base >> 2, h1, h2);
+    s[0] = (h1 & 0xFFFFU) >= c.thresh ? c.scale : 0.f;
+    s[1] = (h1 >> 16) >= c.thresh ? c.scale : 0.f;
+    s[2] = (h2 & 0xFFFFU) >= c.thresh ? c.scale : 0.f;
+    s[3] = (h2 >> 16) >= c.thresh ? c.scale : 0.f;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] = drop_scale(c, base + e);
+  }
 }
 
 // ---- wave helpers (wave = 64 lanes) ------------------------------------------------------

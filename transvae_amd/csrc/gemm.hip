@@ -97,18 +97,18 @@ __device__ inline void stage_fix(float4 (&st)[BK / 8], int row0, int nrows, int 
     stage_pos<BK, KM>(f, row, k);
     int gr = row0 + row, gk = k0 + k;
     float* pv = reinterpret_cast<float*>(&st[j]);
+    float ks[4] = {1.f, 1.f, 1.f, 1.f};
+    if (DROP) {
+      // element (m,k) of A carries the keep-scale of the dropped-out tensor it is the gradient of;
+      // the four elements of a float4 are consecutive indices of that tensor in either layout
+      drop_scale4(dc, KM ? (uint32_t)gk * (uint32_t)dropM + (uint32_t)gr
+                         : (uint32_t)gr * (uint32_t)dropK + (uint32_t)gk, ks);
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       int rr = KM ? gr + e : gr, kk = KM ? gk : gk + e;
       const bool ok = rr < nrows && kk < kend;
-      float v = ok ? pv[e] : 0.f;
-      if (DROP) {
-        // element (m,k) of A carries the keep-scale of the dropped-out tensor it is the gradient of
-        uint32_t idx = KM ? (uint32_t)kk * (uint32_t)dropM + (uint32_t)rr
-                          : (uint32_t)rr * (uint32_t)dropK + (uint32_t)kk;
-        v *= drop_scale(dc, idx);
-      }
-      pv[e] = v;
+      pv[e] = ok ? pv[e] * ks[e] : 0.f;
     }
   }
 }
@@ -360,9 +360,10 @@ void gemm_kernel(GemmArgs g) {
             for (int e = 0; e < 4; ++e) o[e] = mm[e] > 0.f ? o[e] : 0.f;
           } else {
             if (de.on) {
-              const uint32_t base = (uint32_t)grow * (uint32_t)g.N + (uint32_t)gcol;
+              float ks[4];
+              drop_scale4(de, (uint32_t)grow * (uint32_t)g.N + (uint32_t)gcol, ks);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] *= drop_scale(de, base + e);
+              for (int e = 0; e < 4; ++e) o[e] *= ks[e];
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] += mm[e];      // zero when there is no residual

@@ -166,11 +166,13 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
     float4 w = *reinterpret_cast<const float4*>(&lut[(size_t)id * d + c]);
     float4 q = *reinterpret_cast<const float4*>(&pe[(size_t)t * d + c]);
     uint32_t base = (uint32_t)row * (uint32_t)d + (uint32_t)c;
+    float ks[4];
+    drop_scale4(dc, base, ks);
     float4 o;
-    o.x = (w.x * sq + q.x) * drop_scale(dc, base + 0);
-    o.y = (w.y * sq + q.y) * drop_scale(dc, base + 1);
-    o.z = (w.z * sq + q.z) * drop_scale(dc, base + 2);
-    o.w = (w.w * sq + q.w) * drop_scale(dc, base + 3);
+    o.x = (w.x * sq + q.x) * ks[0];
+    o.y = (w.y * sq + q.y) * ks[1];
+    o.z = (w.z * sq + q.z) * ks[2];
+    o.w = (w.w * sq + q.w) * ks[3];
     *reinterpret_cast<float4*>(&out[(size_t)row * d + c]) = o;
   }
 }

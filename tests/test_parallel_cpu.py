@@ -107,3 +107,90 @@ def test_grad_sink_counts_multi_use_parameters():
     sink.done(b); sink.done(a)
     assert done == [b.data_ptr(), a.data_ptr()]
     assert sink.target(a) is a.grad and a.grad.shape == a.shape
+
+
+# ---- a parameter whose gradient is added into param.grad by its own "kernel" (the sink route) ------
+class _DirectLinear(torch.autograd.Function):
+    """y = x W^T whose backward adds dW straight into W.grad and returns None for W, the way the HIP
+    Functions do inside VAEShell.train_step.  autograd still runs W's post-accumulate hook, which the
+    bucket bookkeeping must not count as a second completion (that launched buckets early once)."""
+
+    @staticmethod
+    def forward(ctx, x, W):
+        from transvae_amd import ops
+        ops._note_use(W)
+        ctx.save_for_backward(x, W)
+        return x @ W.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        from transvae_amd import ops
+        x, W = ctx.saved_tensors
+        sink = ops._sink[0]
+        sink.target(W).add_(dy.t() @ x)
+        sink.done(W)
+        return dy @ W, None
+
+
+class _Mixed(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.a = torch.nn.Linear(16, 32)
+        self.w1 = torch.nn.Parameter(torch.randn(32, 32) * 0.2)
+        self.w2 = torch.nn.Parameter(torch.randn(32, 32) * 0.2)
+        self.b = torch.nn.Linear(32, 4)
+
+    def forward(self, x):
+        h = torch.tanh(self.a(x))
+        h = torch.tanh(_DirectLinear.apply(h, self.w1))
+        h = torch.tanh(_DirectLinear.apply(h, self.w2))
+        return self.b(h)
+
+    def plain(self, x):
+        h = torch.tanh(self.a(x))
+        return self.b(torch.tanh(torch.tanh(h @ self.w1.t()) @ self.w2.t()))
+
+
+def _mixed_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from transvae_amd import ops
+    from transvae_amd.parallel import DataParallel
+    model = _Mixed()
+    dp = DataParallel(_Shell(model), n_buckets=2, overlap=True, reduce="sum")
+    g = torch.Generator().manual_seed(5)
+    x, y = torch.randn(8, 16, generator=g), torch.randn(8, 4, generator=g)
+    xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+    dp.sink.pending.clear()
+    with ops.direct_grads(dp.sink):
+        loss = ((model(xs) - ys) ** 2).mean()
+        dp.arm()
+        loss.backward()
+    launched_early = len(dp._launched)
+    dp.finish()
+    q.put((rank, dp.arena.flat.numpy().copy(), launched_early))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_direct_accumulation_parameters_complete_once():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mixed_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    model = _Mixed()
+    g = torch.Generator().manual_seed(5)
+    x, y = torch.randn(8, 16, generator=g), torch.randn(8, 4, generator=g)
+    for r in range(2):
+        ((model.plain(x[r * 4:(r + 1) * 4]) - y[r * 4:(r + 1) * 4]) ** 2).mean().backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in reversed(list(model.parameters()))]).numpy()
+    for rank, flat, early in res:
+        assert early >= 1                                   # at least one bucket went out from a hook
+        assert abs(flat - ref).max() < 1e-6, (rank, abs(flat - ref).max())

@@ -30,15 +30,27 @@ struct AttnArgs {
 
 constexpr float MASK_FILL = -1e9f;
 
+// T[128][DK+4] <- src rows 0..nrows-1 (DK floats each), zero beyond.  Split in two so that the loads
+// of several tiles are all in flight before the first LDS write waits for them.
 template <int DK>
-__device__ inline void load_tile_to_lds(float* __restrict__ T, const float* __restrict__ src, int ld, int nrows, int tid) {
-  // T[128][DK+4] <- src rows 0..nrows-1 (DK floats each), zero beyond
-  constexpr int LS = DK + 4, F4 = DK / 4;
-  for (int f = tid; f < 128 * F4; f += 256) {
-    int row = f / F4, c = (f % F4) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < nrows) v = *reinterpret_cast<const float4*>(src + (size_t)row * ld + c);
-    *reinterpret_cast<float4*>(&T[row * LS + c]) = v;
+struct TileRegs { float4 v[128 * (DK / 4) / 256]; };
+
+template <int DK>
+__device__ inline void tile_issue(TileRegs<DK>& R, const float* __restrict__ src, int ld, int nrows, int tid) {
+  constexpr int F4 = DK / 4, NJ = 128 * F4 / 256;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int f = tid + 256 * j, row = f / F4, c = (f % F4) * 4;
+    R.v[j] = *reinterpret_cast<const float4*>(src + (size_t)(row < nrows ? row : 0) * ld + c);
+  }
+}
+template <int DK>
+__device__ inline void tile_commit(const TileRegs<DK>& R, float* __restrict__ T, int nrows, int tid) {
+  constexpr int LS = DK + 4, F4 = DK / 4, NJ = 128 * F4 / 256;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int f = tid + 256 * j, row = f / F4, c = (f % F4) * 4;
+    *reinterpret_cast<float4*>(&T[row * LS + c]) = row < nrows ? R.v[j] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 
@@ -96,13 +108,14 @@ __device__ inline void store_rowmajor(float* __restrict__ rowp, const floatx16 (
 
 // Mask of one (query, 32-key tile) as a 32-bit word, bit j = key 32t + j may be attended.
 // key_bits[t] holds the (B, Lk) key mask of this molecule (bits past Lk are 0).
+template <bool GENERIC>
 __device__ inline uint32_t tile_mask(const AttnArgs& a, int b, int qi, int t, const uint32_t* key_bits) {
   uint32_t m = key_bits[t];
   if (a.causal) {
     const int last = qi - 32 * t;                         // keys 32t .. 32t+last are visible
     m &= last < 0 ? 0U : (last >= 31 ? 0xFFFFFFFFU : ((2U << last) - 1U));
   }
-  if (a.full_mask) {
+  if (GENERIC && a.full_mask) {
     const uint8_t* fm = a.full_mask + ((size_t)b * a.Lq + qi) * a.Lk + 32 * t;
     uint32_t w = 0;
     for (int j = 0; j < 32 && 32 * t + j < a.Lk; ++j) w |= (fm[j] != 0 ? 1U : 0U) << j;
@@ -127,7 +140,9 @@ __device__ inline uint32_t drop_group(size_t prow, int t, int g, int hh) {
 }
 
 // ------------------------------------------------------------------------------- forward
-template <int DK>
+// GENERIC = false: no (B,Lq,Lk) mask and no attention-weight dump -- the train-step instantiation,
+// free of the per-element branches those options need.
+template <int DK, bool GENERIC>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   constexpr int LS = DK + 4, HALF = DK / 2, NU = DK / 32;
   __shared__ __attribute__((aligned(16))) float Ks[128 * LS];
@@ -139,11 +154,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   const bool qvalid = qi < a.Lq;
   const int qs = qvalid ? qi : 0;
 
-  load_tile_to_lds<DK>(Ks, a.k + (size_t)b * a.Lk * a.ldk + head * DK, a.ldk, a.Lk, tid);
-  load_tile_to_lds<DK>(Vs, a.v + (size_t)b * a.Lk * a.ldv + head * DK, a.ldv, a.Lk, tid);
-  load_key_bits(key_bits, a, b, tid);
   float qreg[HALF];
-  load_row_half<HALF>(qreg, a.q + ((size_t)b * a.Lq + qs) * a.ldq + head * DK + hh * HALF, qvalid);
+  {
+    TileRegs<DK> rk, rv;
+    tile_issue<DK>(rk, a.k + (size_t)b * a.Lk * a.ldk + head * DK, a.ldk, a.Lk, tid);
+    tile_issue<DK>(rv, a.v + (size_t)b * a.Lk * a.ldv + head * DK, a.ldv, a.Lk, tid);
+    load_row_half<HALF>(qreg, a.q + ((size_t)b * a.Lq + qs) * a.ldq + head * DK + hh * HALF, qvalid);
+    load_key_bits(key_bits, a, b, tid);
+    tile_commit<DK>(rk, Ks, a.Lk, tid);
+    tile_commit<DK>(rv, Vs, a.Lk, tid);
+  }
   __syncthreads();
 
   DropCfg dc = drop_cfg(a.rng, a.site, a.p);
@@ -152,7 +172,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     st[t] = mma_rows_x_reg<DK>(Ks, 32 * t + r, hh, qreg);
-    const uint32_t mw = tile_mask(a, b, qs, t, key_bits) >> (4 * hh);
+    const uint32_t mw = tile_mask<GENERIC>(a, b, qs, t, key_bits) >> (4 * hh);
     const int nk = a.Lk - 32 * t - 4 * hh;                 // keys of this tile with in-lane offset < nk exist
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -198,7 +218,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
       for (int e = 0; e < 4; ++e) {
         const int i = 4 * g + e;
         float p = st[t][i] * inv;
-        if (a.p_out) {
+        if (GENERIC && a.p_out) {
           const int key = 32 * t + crow(i, hh);
           if (qvalid && key < a.Lk) a.p_out[prow * a.Lk + key] = p;
         }
@@ -220,7 +240,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 // near-uniform source attention of this model that error was 3-4x the reference's own.)
 // Also leaves, for the dK/dV kernel: dsum per row and the dropout keep flags of the row as four
 // 32-bit words (that kernel holds the key on the lane and would need one hash per element).
-template <int DK>
+template <int DK, bool GENERIC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 void attn_bwd_dq_kernel(AttnArgs a) {
   constexpr int LS = DK + 4, HALF = DK / 2, NU = DK / 32;
@@ -233,9 +253,6 @@ void attn_bwd_dq_kernel(AttnArgs a) {
   const bool qvalid = qi < a.Lq;
   const int qs = qvalid ? qi : 0;
 
-  load_tile_to_lds<DK>(Ks, a.k + (size_t)b * a.Lk * a.ldk + head * DK, a.ldk, a.Lk, tid);
-  load_tile_to_lds<DK>(Vs, a.v + (size_t)b * a.Lk * a.ldv + head * DK, a.ldv, a.Lk, tid);
-  load_key_bits(key_bits, a, b, tid);
   const size_t prow = ((size_t)(b * a.h + head) * a.Lq + qi);
   const float row_mx = qvalid ? a.lse_in[2 * prow] : 0.f;
   const float row_ls = qvalid ? a.lse_in[2 * prow + 1] : 0.f;
@@ -244,8 +261,16 @@ void attn_bwd_dq_kernel(AttnArgs a) {
   uint32_t mwt[4], kwt[4];
   {
     float qreg[HALF], doreg[HALF];
-    load_row_half<HALF>(qreg, a.q + ((size_t)b * a.Lq + qs) * a.ldq + head * DK + hh * HALF, qvalid);
-    load_row_half<HALF>(doreg, a.d_o + ((size_t)b * a.Lq + qs) * a.lddo + head * DK + hh * HALF, qvalid);
+    {
+      TileRegs<DK> rk, rv;
+      tile_issue<DK>(rk, a.k + (size_t)b * a.Lk * a.ldk + head * DK, a.ldk, a.Lk, tid);
+      tile_issue<DK>(rv, a.v + (size_t)b * a.Lk * a.ldv + head * DK, a.ldv, a.Lk, tid);
+      load_row_half<HALF>(qreg, a.q + ((size_t)b * a.Lq + qs) * a.ldq + head * DK + hh * HALF, qvalid);
+      load_row_half<HALF>(doreg, a.d_o + ((size_t)b * a.Lq + qs) * a.lddo + head * DK + hh * HALF, qvalid);
+      load_key_bits(key_bits, a, b, tid);
+      tile_commit<DK>(rk, Ks, a.Lk, tid);
+      tile_commit<DK>(rv, Vs, a.Lk, tid);
+    }
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -256,7 +281,7 @@ void attn_bwd_dq_kernel(AttnArgs a) {
   float dsum = 0.f, psum = 0.f;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const uint32_t mw = tile_mask(a, b, qs, t, key_bits) >> (4 * hh);
+    const uint32_t mw = tile_mask<GENERIC>(a, b, qs, t, key_bits) >> (4 * hh);
     mwt[t] = mw;
     const int nk = qvalid ? a.Lk - 32 * t - 4 * hh : 0;
     uint32_t kw = 0;
@@ -317,36 +342,40 @@ void attn_bwd_dq_kernel(AttnArgs a) {
 // Key on the lane: S = Q K^T and dP = dO V^T come out as [query regs][key lanes], which is the
 // B operand of dV^T = dO^T P and dK^T = Q^T dS directly.  Row statistics, dsum and the dropout keep
 // words come from the dQ kernel's workspace (one LDS broadcast read per query).
-template <int DK>
+template <int DK, bool GENERIC>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
   constexpr int LS = DK + 4, HALF = DK / 2, NU = DK / 32;
   __shared__ __attribute__((aligned(16))) float Qs[128 * LS];
   __shared__ __attribute__((aligned(16))) float Gs[128 * LS];   // dO
-  __shared__ float mx_s[128], ls_s[128], dsum_s[128];
-  __shared__ uint32_t keep_s[128][4];
+  __shared__ __attribute__((aligned(16))) float4 stat_s[128];     // {row max, 1/row sum, dsum, -} per query
+  __shared__ __attribute__((aligned(16))) uint32_t keep_s[128][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const int b = blockIdx.x / a.h, head = blockIdx.x % a.h;
   const int key = 32 * wave + r;
   const bool kvalid = key < a.Lk;
   const int ks = kvalid ? key : 0;
 
-  load_tile_to_lds<DK>(Qs, a.q + (size_t)b * a.Lq * a.ldq + head * DK, a.ldq, a.Lq, tid);
-  load_tile_to_lds<DK>(Gs, a.d_o + (size_t)b * a.Lq * a.lddo + head * DK, a.lddo, a.Lq, tid);
   DropCfg dc = drop_cfg(a.rng, a.site, a.p);
+  float kreg[HALF], vreg[HALF];
+  {
+    TileRegs<DK> rq, rg;
+    tile_issue<DK>(rq, a.q + (size_t)b * a.Lq * a.ldq + head * DK, a.ldq, a.Lq, tid);
+    tile_issue<DK>(rg, a.d_o + (size_t)b * a.Lq * a.lddo + head * DK, a.lddo, a.Lq, tid);
+    load_row_half<HALF>(kreg, a.k + ((size_t)b * a.Lk + ks) * a.ldk + head * DK + hh * HALF, kvalid);
+    load_row_half<HALF>(vreg, a.v + ((size_t)b * a.Lk + ks) * a.ldv + head * DK + hh * HALF, kvalid);
+    tile_commit<DK>(rq, Qs, a.Lq, tid);
+    tile_commit<DK>(rg, Gs, a.Lq, tid);
+  }
   if (tid < 128) {
     size_t prow = ((size_t)(b * a.h + head) * a.Lq + tid);
     const bool ok = tid < a.Lq;
-    mx_s[tid] = ok ? a.lse_in[2 * prow] : 0.f;
-    ls_s[tid] = ok ? a.lse_in[2 * prow + 1] : 0.f;
-    dsum_s[tid] = ok ? a.dsum[prow] : 0.f;
+    stat_s[tid] = ok ? make_float4(a.lse_in[2 * prow], a.lse_in[2 * prow + 1], a.dsum[prow], 0.f)
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
     const size_t rows_pad = ((size_t)a.B * a.h * a.Lq + 3) & ~(size_t)3;
     uint4 w = make_uint4(~0U, ~0U, ~0U, ~0U);
     if (ok && dc.on) w = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(a.dsum) + rows_pad + 4 * prow);
     *reinterpret_cast<uint4*>(&keep_s[tid][0]) = w;
   }
-  float kreg[HALF], vreg[HALF];
-  load_row_half<HALF>(kreg, a.k + ((size_t)b * a.Lk + ks) * a.ldk + head * DK + hh * HALF, kvalid);
-  load_row_half<HALF>(vreg, a.v + ((size_t)b * a.Lk + ks) * a.ldv + head * DK + hh * HALF, kvalid);
   const bool kbit = kvalid && (a.key_mask ? a.key_mask[(size_t)b * a.Lk + key] != 0 : true);
   __syncthreads();
 
@@ -364,12 +393,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
       if (kvalid && qi < a.Lq) {
         bool m = kbit;
         if (a.causal) m = m && (key <= qi);
-        if (a.full_mask) m = m && (a.full_mask[((size_t)b * a.Lq + qi) * a.Lk + key] != 0);
+        if (GENERIC && a.full_mask) m = m && (a.full_mask[((size_t)b * a.Lq + qi) * a.Lk + key] != 0);
+        const float4 st = stat_s[qi];
         float sc = m ? s[i] * a.scale : MASK_FILL;
-        float p = expf(sc - mx_s[qi]) * ls_s[qi];
+        float p = expf(sc - st.x) * st.y;
         float ksc = ((keep_s[qi][wave] >> r) & 1U) ? dc.scale : 0.f;
         pt = p * ksc;
-        if (m) ds = p * (dp[i] * ksc - dsum_s[qi]) * a.scale;
+        if (m) ds = p * (dp[i] * ksc - st.z) * a.scale;
       }
       s[i] = pt;
       dp[i] = ds;
@@ -414,8 +444,14 @@ extern "C" int tvae_attn_fwd(const float* q, int ldq, const float* k, int ldk, c
   a.key_mask = key_mask; a.full_mask = full_mask; a.causal = causal;
   a.B = B; a.h = h; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.rng = rng; a.site = site; a.p = p_drop;
   hipStream_t s = (hipStream_t)stream;
-  if (dk == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, dim3(B * h), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(attn_fwd_kernel<32>, dim3(B * h), dim3(256), 0, s, a);
+  const bool generic = full_mask || p_out;
+  if (dk == 64) {
+    if (generic) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), dim3(B * h), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<64, false>), dim3(B * h), dim3(256), 0, s, a);
+  } else {
+    if (generic) hipLaunchKernelGGL((attn_fwd_kernel<32, true>), dim3(B * h), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<32, false>), dim3(B * h), dim3(256), 0, s, a);
+  }
   TVAE_LAUNCH_CHECK("tvae_attn_fwd");
   return TVAE_OK;
 }
@@ -438,12 +474,23 @@ extern "C" int tvae_attn_bwd(const float* q, int ldq, const float* k, int ldk, c
   a.key_mask = key_mask; a.full_mask = full_mask; a.causal = causal;
   a.B = B; a.h = h; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.rng = rng; a.site = site; a.p = p_drop;
   hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(B * h), block(256);
   if (dk == 64) {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, dim3(B * h), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, dim3(B * h), dim3(256), 0, s, a);
+    if (full_mask) {
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<64, true>), grid, block, 0, s, a);
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, true>), grid, block, 0, s, a);
+    } else {
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<64, false>), grid, block, 0, s, a);
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, false>), grid, block, 0, s, a);
+    }
   } else {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, dim3(B * h), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, dim3(B * h), dim3(256), 0, s, a);
+    if (full_mask) {
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<32, true>), grid, block, 0, s, a);
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<32, true>), grid, block, 0, s, a);
+    } else {
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<32, false>), grid, block, 0, s, a);
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<32, false>), grid, block, 0, s, a);
+    }
   }
   TVAE_LAUNCH_CHECK("tvae_attn_bwd");
   return TVAE_OK;

@@ -10,13 +10,45 @@ backward; xGMI is point-to-point, so few large messages (3-4 buckets of ~8 MB fo
 is the shape that suits it.  The 1/world averaging is folded into the fused Adam launch
 (grad_scale), so no extra pass over the gradients is needed.
 
-Semantics: standard data parallelism -- every rank computes the reference's chunk-mean loss on its
-own molecules and gradients are averaged.  The weighted-mean CE normaliser differs per rank
-(SURVEY.md 8e), so this equals the single-GPU gradient on the concatenated batch only up to that
-normaliser (1e-4..1e-3 relative); documented in DESIGN.md.
+Semantics.  The reference normalises the loss per CHUNK (BATCH_SIZE / BATCH_CHUNKS molecules, weighted
+CE denominator included) and SUMS the chunk gradients (trans_models.py:202-236).  Ranks hold whole
+chunks, so no normaliser ever spans two ranks and nothing but the gradients has to be exchanged:
+  reduce='sum'   the step is exactly the reference's step with BATCH_SIZE x world molecules in
+                 BATCH_CHUNKS x world chunks (checked on the GPU by tests/test_parallel_gpu.py);
+  reduce='mean'  (default) the summed gradient divided by world, i.e. the usual data-parallel
+                 convention; Adam's update is invariant to that factor up to its eps of 1e-9.
 """
 import torch
 import torch.distributed as dist
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+def _host_staged():
+    "gloo moves host memory: device buffers are staged through the host (CPU-side tests and rehearsals only)"
+    return dist.get_backend() == "gloo"
+
+
+def _all_reduce_sum(t):
+    "launch a SUM all-reduce of a flat fp32 tensor; returns an object with .wait()"
+    if t.is_cuda and _host_staged():
+        host = t.cpu()                     # synchronises with the stream that produced the gradients
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        t.copy_(host)
+        return _Done()
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+
+
+def _broadcast(t, src=0):
+    if t.is_cuda and _host_staged():
+        host = t.cpu()
+        dist.broadcast(host, src=src)
+        t.copy_(host)
+    else:
+        dist.broadcast(t, src=src)
 
 
 class GradArena:
@@ -48,9 +80,11 @@ class GradArena:
 class DataParallel:
     """Wraps a VAEShell: ``step(data, beta)`` = VAEShell.train_step with bucketed gradient all-reduce."""
 
-    def __init__(self, vae, n_buckets=4, overlap=True):
+    def __init__(self, vae, n_buckets=4, overlap=True, reduce="mean"):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
+        if reduce not in ("mean", "sum"):
+            raise ValueError("reduce must be 'mean' or 'sum'")
         self.vae = vae
         self.world = dist.get_world_size()
         self.arena = GradArena(vae.model, n_buckets)
@@ -64,23 +98,33 @@ class DataParallel:
         # gradient still travels through autograd (conv / deconv kernels) through a hook
         from . import ops
         self.sink = ops.GradSink(on_complete=self._hook if overlap else None)
+        self._seen = set()
         if overlap:
             for p in self.arena.params:
-                p.register_post_accumulate_grad_hook(self._hook)
+                p.register_post_accumulate_grad_hook(self._autograd_hook)
         # parameters start identical on every rank
         for p in vae.model.parameters():
-            dist.broadcast(p.data, src=0)
-        self._set_grad_scale(1.0 / self.world)
+            _broadcast(p.data, src=0)
+        self._set_grad_scale(1.0 / self.world if reduce == "mean" else 1.0)
 
     def _set_grad_scale(self, s):
         self.vae.optimizer.optimizer.grad_scale = s
+
+    def _autograd_hook(self, p):
+        # autograd runs the post-accumulate hook of EVERY parameter it visits, including those whose
+        # Function returned no gradient because its kernels add into param.grad themselves; for
+        # those only the sink knows when the last contribution has been launched
+        if p.data_ptr() in self.sink.pending:
+            return
+        self._hook(p)
 
     def _hook(self, p):
         if not self._armed:
             return
         bi = self.arena.bucket_of.get(p.data_ptr())
-        if bi is None:
+        if bi is None or p.data_ptr() in self._seen:
             return
+        self._seen.add(p.data_ptr())
         self._count[bi] += 1
         if self._count[bi] >= self.arena.buckets[bi][2] and bi not in self._launched:
             self._launch(bi)
@@ -88,7 +132,7 @@ class DataParallel:
     def _launch(self, bi):
         s, e, _ = self.arena.buckets[bi]
         self._launched.add(bi)
-        self._pending.append(dist.all_reduce(self.arena.flat[s:e], op=dist.ReduceOp.SUM, async_op=True))
+        self._pending.append(_all_reduce_sum(self.arena.flat[s:e]))
 
     def arm(self):
         "call before the backward of the last accumulation chunk"
@@ -96,6 +140,7 @@ class DataParallel:
         self._count = [0] * len(self.arena.buckets)
         self._pending = []
         self._launched = set()
+        self._seen = set()
 
     def finish(self):
         "after the last backward: reduce whatever was not launched from hooks, wait for all buckets"

@@ -22,7 +22,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}     # MI355X_MICROARCH.md: dense MFMA peaks
+# MI355X_MICROARCH.md dense MFMA peaks; f32x3 = fp32-accurate products from six bf16 MFMAs: bf16 peak / 6
+PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "f32x3": 2500.0 / 6}
 FLOP_PER_MOL_FWD_BWD = 5.940e9                      # trans4x-256, SURVEY.md 8(d)
 FLOP_PER_MOL_DECODE = 1.196e9
 
@@ -99,12 +100,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32")
+    ap.add_argument("--dtype", choices=["fp32", "f32x3", "bf16"], default="fp32")
     ap.add_argument("--batch", type=int, default=500)
     ap.add_argument("--chunks", type=int, default=5)
     ap.add_argument("--decode-n", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--no-extra-modes", action="store_true", help="skip the secondary timings in the other GEMM arithmetics")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -139,18 +141,22 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        table = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    def timed(n_warm, n_steps):
+        for _ in range(n_warm):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            tab = step()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, tab
+
+    dt, table = timed(args.warmup, args.steps)
     last_loss = float(table[:, 0].mean().item())
     tokens = world * args.batch * 126 * args.steps
     value = tokens / dt
@@ -159,7 +165,7 @@ def main():
         "metric": "train tokens/s (fwd+bwd) + decoded mols/s, trans4x-256, 1/2/4/8 MI355X",
         "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
+        "vs_baseline": None, "dtype": {"fp32": "f32", "f32x3": "f32 (GEMM products as 3xbf16 splits, fp32 accumulate)", "bf16": "bf16"}[args.dtype], "data": "synthetic",
         "config": {"workload": "trans4x-256 ZINC-vocab train step (fwd+loss+bwd+Noam/Adam), batch %d per GPU in one pass with the "
                                "reference's %d x %d chunk-wise loss normalisation, max_len 126, dropout 0.1, synthetic "
                                "SMILES-shaped tokens, synthetic checkpoint"
@@ -170,6 +176,20 @@ def main():
         "train_algorithmic_tflops": world * args.batch * FLOP_PER_MOL_FWD_BWD * args.steps / dt / 1e12,
         "train_frac_of_mfma_peak": (args.batch * FLOP_PER_MOL_FWD_BWD * args.steps / dt / 1e12) / PEAK_TFLOPS[args.dtype],
     }
+
+    # ---- the same step in the other GEMM arithmetics (secondary numbers; `value` is args.dtype) -----
+    if not args.no_extra_modes:
+        others = {}
+        for mode in ("fp32", "f32x3", "bf16"):
+            if mode == args.dtype:
+                continue
+            ops.set_compute_dtype(mode)
+            dto, _ = timed(2, args.steps)
+            others[mode] = {"value": tokens / dto, "unit": "tokens/s", "ms_per_step": 1e3 * dto / args.steps,
+                            "parity": "fp32 tolerances (tests/test_model_gpu.py runs in this mode too)" if mode != "bf16"
+                                      else "1e-2 (operands rounded to bf16)"}
+        ops.set_compute_dtype(args.dtype)
+        out["other_gemm_modes"] = others
 
     # ---- greedy decode (KV-cached), sharded by latent batch: every rank decodes its own slab ------
     if not args.no_decode:

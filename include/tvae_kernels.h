@@ -18,7 +18,10 @@
  *   - matrices are row-major fp32; "ld" is the row stride in elements;
  *   - `dtype`: TVAE_F32 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), TVAE_BF16 = operands
  *     rounded to bf16 on the way into LDS, fp32 accumulate (v_mfma_f32_32x32x16_bf16);
- *     tensors in HBM stay fp32 in both modes;
+ *     TVAE_F32X3 = every fp32 operand split exactly into hi+mid+lo bf16 and the six partial
+ *     products >= 2^-24 accumulated in fp32 on the bf16 matrix cores (error at fp32's own
+ *     rounding level; GEMM only, the other kernels compute in fp32); tensors in HBM stay fp32
+ *     in all modes;
  *   - dropout: `rng` points at two device uint32 {seed, step}; `site` names the call site;
  *     the keep-mask is a counter-based hash of (seed, step, site, element index), so the
  *     backward kernels regenerate it instead of storing it.  p == 0 or rng == NULL: off.
@@ -42,6 +45,7 @@ extern "C" {
 
 #define TVAE_F32 0
 #define TVAE_BF16 1
+#define TVAE_F32X3 2   /* fp32-accurate GEMM from six bf16 MFMAs on exact 3-way bf16 splits of the operands */
 
 /* gemm flags */
 #define TVAE_GEMM_RELU 1        /* v = max(v, 0) after bias */

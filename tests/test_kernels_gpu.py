@@ -411,3 +411,38 @@ def test_sublayer_functions_match_oracle():
             assert float(t.grad.abs().max()) < 1e-4 * float(dout.abs().max())
         else:
             assert rel_l2(t.grad.cpu(), gref) < 1e-5, n
+
+
+# ---- fp32-accurate GEMM on the bf16 matrix cores (dtype f32x3) -------------------------------------
+@pytest.mark.parametrize("M,N,K", [(777, 256, 256), (1500, 1024, 256), (640, 256, 1024), (300, 260, 2304), (130, 132, 40)])
+def test_gemm_f32x3_is_as_accurate_as_fp32(M, N, K):
+    """Every GEMM role (forward with bias/ReLU/residual, data gradient, weight gradient with the fused
+    bias gradient) in 3xbf16-split arithmetic against an fp64 product: the error must be at the level
+    of the exact-fp32 kernel's (both are printed), far from bf16's 2e-3."""
+    from transvae_amd import ops
+    torch.manual_seed(M + N + K)
+    x = torch.randn(M, K, device=dev())
+    w = torch.randn(N, K, device=dev()) * 0.05
+    b = torch.randn(N, device=dev())
+    res = torch.randn(M, N, device=dev())
+    dy = torch.randn(M, N, device=dev())
+    ref_f = torch.relu(x.double() @ w.double().t() + b.double()) + res.double()
+    ref_d = dy.double() @ w.double()
+    ref_w = dy.double().t() @ x.double()
+    ref_b = dy.double().sum(0)
+    errs = {}
+    prev = ops.compute_dtype()
+    try:
+        for mode in ("fp32", "f32x3"):
+            ops.set_compute_dtype(mode)
+            yf = ops.linear_fwd(x, w, b, relu=True, residual=res)
+            yd = ops.linear_dgrad(dy, w)
+            yw, yb = ops.linear_wgrad(dy, x)
+            errs[mode] = [rel_l2(yf.cpu(), ref_f.cpu()), rel_l2(yd.cpu(), ref_d.cpu()), rel_l2(yw.cpu(), ref_w.cpu()),
+                          rel_l2(yb.cpu(), ref_b.cpu())]
+    finally:
+        ops.set_compute_dtype(prev)
+    print("rel-L2 vs fp64 (fwd, dgrad, wgrad, bias grad): fp32 %s  f32x3 %s" %
+          (["%.1e" % e for e in errs["fp32"]], ["%.1e" % e for e in errs["f32x3"]]))
+    for e3, e1 in zip(errs["f32x3"], errs["fp32"]):
+        assert e3 < max(2.0 * e1, 3e-7), (errs)

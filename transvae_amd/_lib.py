@@ -13,7 +13,7 @@ import torch  # noqa: F401  -- FIRST: torch bundles its own libamdhip64; loading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtvae_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F32X3 = 0, 1, 2
 GEMM_RELU, GEMM_ACCUM, GEMM_A_KMAJOR, GEMM_B_KMAJOR, GEMM_SPLITK, GEMM_A_DROPMASK, GEMM_RELUMASK = 1, 2, 4, 8, 16, 32, 64
 
 _vp, _i, _f, _u = C.c_void_p, C.c_int, C.c_float, C.c_uint32

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtvae_hip.so")
-SOURCES = ["gemm.hip", "rowops.hip", "attention.hip", "lossopt.hip"]
+SOURCES = ["gemm.hip", "gemm3.hip", "rowops.hip", "attention.hip", "lossopt.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
@@ -27,7 +27,8 @@ def _stale(target, deps):
 
 def build_lib(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "tvae_kernels.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"),
+               os.path.join(HERE, "..", "include", "tvae_kernels.h")]
     objs, jobs = [], []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)

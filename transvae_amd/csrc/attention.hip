@@ -437,7 +437,7 @@ extern "C" int tvae_attn_fwd(const float* q, int ldq, const float* k, int ldk, c
   const void* ptrs[] = {q, k, v, o};
   int rc = check_common("tvae_attn_fwd", B, h, Lq, Lk, dk, lds, 4, ptrs, 4, rng && p_drop > 0.f);
   if (rc) return rc;
-  TVAE_CHECK(dtype == TVAE_F32 || dtype == TVAE_BF16, TVAE_E_DTYPE, "tvae_attn_fwd: dtype %d", dtype);
+  TVAE_CHECK(dtype == TVAE_F32 || dtype == TVAE_BF16 || dtype == TVAE_F32X3, TVAE_E_DTYPE, "tvae_attn_fwd: dtype %d", dtype);
   AttnArgs a = {};
   a.q = q; a.k = k; a.v = v; a.o_out = o; a.lse_out = lse; a.p_out = p_out;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
@@ -466,7 +466,7 @@ extern "C" int tvae_attn_bwd(const float* q, int ldq, const float* k, int ldk, c
   int rc = check_common("tvae_attn_bwd", B, h, Lq, Lk, dk, lds, 8, ptrs, 8, rng && p_drop > 0.f);
   if (rc) return rc;
   TVAE_CHECK(lse && dsum && aligned16(dsum), TVAE_E_NULL, "tvae_attn_bwd: lse / dsum workspace missing or not 16-byte aligned");
-  TVAE_CHECK(dtype == TVAE_F32 || dtype == TVAE_BF16, TVAE_E_DTYPE, "tvae_attn_bwd: dtype %d", dtype);
+  TVAE_CHECK(dtype == TVAE_F32 || dtype == TVAE_BF16 || dtype == TVAE_F32X3, TVAE_E_DTYPE, "tvae_attn_bwd: dtype %d", dtype);
   AttnArgs a = {};
   a.q = q; a.k = k; a.v = v; a.o = o; a.d_o = d_o; a.lse_in = lse;
   a.dq = dq; a.dk = dk_; a.dv = dv; a.dsum = dsum;

@@ -16,12 +16,11 @@
 // [k][row] (+4) and read with conflict-free ds_read_b32.
 #include <stdlib.h>
 #include "common.h"
+#include "gemm_common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128;
 constexpr int LDS_KM = BM + 4;    // [k][row] stride (floats)
-constexpr int FLAG_VEC_EPILOGUE = 1 << 20;   // internal: float4 epilogue through LDS (set by the host wrapper)
 
 // The k-depth of a tile is a template parameter: BK = 32 halves the barrier count, BK = 16 halves
 // LDS and the fragment registers so that three workgroups share a CU instead of two (the prologue
@@ -34,15 +33,6 @@ struct Tile {
   static constexpr int FLOATS = (BM * KC > BK * LDS_KM) ? BM * KC : BK * LDS_KM;
   static constexpr int NJ = BK / 8;                 // float4 per thread per operand tile
   static constexpr int HK = BK / 2;                 // k values owned by one lane half
-};
-
-struct GemmArgs {
-  const float* A; const float* B; float* C; const float* bias; const float* res;
-  int lda, ldb, ldc, ldr, M, N, K;
-  float alpha; int flags;
-  const uint32_t* rng; uint32_t site; float p;
-  int k_per_split;
-  float* a_rowsum;   // A_KMAJOR only: a_rowsum[m] += sum_k A(m,k) (bias gradient fused into wgrad)
 };
 
 __device__ inline unsigned short f2bf(float f) {
@@ -153,15 +143,7 @@ void gemm_kernel(GemmArgs g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, hh = lane >> 5;
   const int ntn = (g.N + BN - 1) / BN;
-  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (id % 8 shares an L2),
-  // so give each XCD a CONTIGUOUS run of tiles -- the ntn column tiles that re-read one A row
-  // panel then hit the same L2 instead of fetching the panel once per XCD.  (Bijective for any
-  // grid size; placement is a speed matter only.)
-  int wgid;
-  {
-    const int nwg = gridDim.x, id = blockIdx.x, q = nwg >> 3, rr = nwg & 7, xcd = id & 7;
-    wgid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (id >> 3);
-  }
+  const int wgid = xcd_tile_id();
   const int tile_n = wgid % ntn, tile_m = wgid / ntn;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int kbeg = blockIdx.z * g.k_per_split;
@@ -302,108 +284,7 @@ void gemm_kernel(GemmArgs g) {
     }
   }
 
-  // ---- epilogue ----------------------------------------------------------------------------
-  const bool relu = g.flags & TVAE_GEMM_RELU, accum = g.flags & TVAE_GEMM_ACCUM;
-  const bool splitk = g.flags & TVAE_GEMM_SPLITK, relumask = g.flags & 64;
-  DropCfg de = drop_cfg((g.flags & TVAE_GEMM_A_DROPMASK) ? nullptr : g.rng, g.site, g.p);
-  const bool lead = (blockIdx.z == 0);
-  if (g.flags & FLAG_VEC_EPILOGUE) {
-    // Row-per-lane accumulator stores are issue-bound (64 dword stores per lane).  Turn the wave's
-    // 64x64 tile through its own LDS slab instead and leave as 16 float4 per lane: 16 lanes cover
-    // one 256-byte row segment, residual / saved-activation reads are float4 too.
-    if (do_rowsum) __syncthreads();
-    constexpr int ES = 68;
-    constexpr int EB = (BK == 16) ? 2 : 4;     // row segments in flight per lane (register budget of the 4-waves/SIMD build)
-    static_assert(4 * 32 * ES <= 4 * TILE_FLOATS, "epilogue slabs must fit the staging buffers");
-    float* T = lds + wave * (32 * ES);
-    const int c = (lane & 15) * 4;
-    const int gcol = n0 + wn * 64 + c;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g.bias && gcol < g.N) bv = *reinterpret_cast<const float4*>(g.bias + gcol);
-    const float* __restrict__ aux = g.res;      // residual or saved activation; must not alias C
-    const bool need_aux = (aux != nullptr);
-    const bool col_ok = gcol < g.N;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {               // 32 rows per pass (LDS ops of one wave stay in order)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) T[crow(q, hh) * ES + 32 * j + r] = acc[i][j][q];
-      for (int it0 = 0; it0 < 8; it0 += EB) {
-        // batch of EB row segments: issue every global read first, then compute, then store
-        float4 m[EB], old[EB], v[EB];
-        bool ok[EB];
-        size_t coff[EB];
-#pragma unroll
-        for (int u = 0; u < EB; ++u) {
-          const int rl = (it0 + u) * 4 + (lane >> 4);
-          const int grow = m0 + wm * 64 + 32 * i + rl;
-          ok[u] = col_ok && grow < g.M;
-          coff[u] = (size_t)(ok[u] ? grow : 0) * g.ldc + (col_ok ? gcol : 0);
-          v[u] = *reinterpret_cast<const float4*>(&T[rl * ES + c]);
-          m[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          old[u] = m[u];
-          if (need_aux) m[u] = *reinterpret_cast<const float4*>(aux + (size_t)(ok[u] ? grow : 0) * g.ldr + (col_ok ? gcol : 0));
-          if (accum) old[u] = *reinterpret_cast<const float4*>(g.C + coff[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < EB; ++u) {
-          const int grow = m0 + wm * 64 + 32 * i + (it0 + u) * 4 + (lane >> 4);
-          float o[4] = {v[u].x * g.alpha + bv.x, v[u].y * g.alpha + bv.y, v[u].z * g.alpha + bv.z, v[u].w * g.alpha + bv.w};
-          const float mm[4] = {m[u].x, m[u].y, m[u].z, m[u].w};
-          if (relu) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
-          }
-          if (relumask) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = mm[e] > 0.f ? o[e] : 0.f;
-          } else {
-            if (de.on) {
-              float ks[4];
-              drop_scale4(de, (uint32_t)grow * (uint32_t)g.N + (uint32_t)gcol, ks);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] *= ks[e];
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] += mm[e];      // zero when there is no residual
-          }
-          if (ok[u])
-            *reinterpret_cast<float4*>(g.C + coff[u]) =
-                make_float4(o[0] + old[u].x, o[1] + old[u].y, o[2] + old[u].z, o[3] + old[u].w);
-        }
-      }
-    }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int col = n0 + wn * 64 + 32 * j + r;
-      if (col >= g.N) continue;
-      float bv = (g.bias && lead) ? g.bias[col] : 0.f;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        int row = m0 + wm * 64 + 32 * i + crow(q, hh);
-        if (row >= g.M) continue;
-        float v = acc[i][j][q] * g.alpha + bv;
-        if (splitk) {
-          atomicAdd(&g.C[(size_t)row * g.ldc + col], v);
-          continue;
-        }
-        if (relu) v = fmaxf(v, 0.f);
-        if (relumask) {
-          // backward of relu(+dropout): pass the gradient where the saved activation is > 0
-          v = (g.res[(size_t)row * g.ldr + col] > 0.f) ? v : 0.f;
-        } else {
-          v *= drop_scale(de, (uint32_t)row * (uint32_t)g.N + (uint32_t)col);
-          if (g.res) v += g.res[(size_t)row * g.ldr + col];
-        }
-        float* dst = &g.C[(size_t)row * g.ldc + col];
-        *dst = accum ? (*dst + v) : v;
-      }
-    }
+  gemm_epilogue<(BK == 16) ? 2 : 4>(g, acc, lds, m0, n0, do_rowsum);
 }
 
 template <int BK, bool A_KM, bool B_KM, bool ALIGNED, bool BF16>
@@ -449,13 +330,15 @@ int tile_depth(bool bf16, int tiles, bool splitk) {
 
 }  // namespace
 
+void tvae_gemm3_launch(const void* gp, int tiles, int splits, bool a_km, bool b_km, bool drop, hipStream_t s);   // gemm3.hip
+
 extern "C" int tvae_gemm(const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                          int M, int N, int K, const float* bias, const float* residual, int ldr,
                          float alpha, int flags, const uint32_t* rng, uint32_t site, float p_drop,
                          float* a_rowsum, int dtype, void* stream) {
   TVAE_CHECK(A && B && C, TVAE_E_NULL, "tvae_gemm: null operand");
   TVAE_CHECK(M > 0 && N > 0 && K > 0, TVAE_E_SHAPE, "tvae_gemm: M,N,K must be positive (%d,%d,%d)", M, N, K);
-  TVAE_CHECK(dtype == TVAE_F32 || dtype == TVAE_BF16, TVAE_E_DTYPE, "tvae_gemm: dtype %d", dtype);
+  TVAE_CHECK(dtype == TVAE_F32 || dtype == TVAE_BF16 || dtype == TVAE_F32X3, TVAE_E_DTYPE, "tvae_gemm: dtype %d", dtype);
   const bool a_km = flags & TVAE_GEMM_A_KMAJOR, b_km = flags & TVAE_GEMM_B_KMAJOR;
   // lda / ldb may be SMALLER than the contiguous extent: overlapping rows are how the conv
   // bottlenecks present their im2col operands (lda = C_in < K = k*C_in).  Only C must not overlap.
@@ -483,8 +366,11 @@ extern "C" int tvae_gemm(const float* A, int lda, const float* B, int ldb, float
     g.flags |= FLAG_VEC_EPILOGUE;
   TVAE_CHECK(!a_rowsum || a_km, TVAE_E_SHAPE, "tvae_gemm: a_rowsum needs a k-major A (wgrad form)");
   const bool bf16 = dtype == TVAE_BF16;
+  const bool drop = (flags & TVAE_GEMM_A_DROPMASK) && rng && p_drop > 0.f;
+  // split-bf16 kernel: aligned operands only; a k-major A with the A-side dropout mask stays on the fp32 kernel
+  const bool x3 = dtype == TVAE_F32X3 && aligned && !(a_km && drop);
   int tiles = cdiv(M, BM) * cdiv(N, BN);
-  const int BK = tile_depth(bf16, tiles, flags & TVAE_GEMM_SPLITK);
+  const int BK = x3 ? 32 : tile_depth(bf16, tiles, flags & TVAE_GEMM_SPLITK);
   int splits = 1;
   if (flags & TVAE_GEMM_SPLITK) {
     // one full round of resident workgroups, each with at least 256 of K: more splits only add
@@ -499,9 +385,13 @@ extern "C" int tvae_gemm(const float* A, int lda, const float* B, int ldb, float
   } else {
     g.k_per_split = cdiv(K, 32) * 32;
   }
-  dim3 grid(tiles, 1, splits);
-  const bool drop = (flags & TVAE_GEMM_A_DROPMASK) && rng && p_drop > 0.f;
   hipStream_t s = (hipStream_t)stream;
+  if (x3) {
+    tvae_gemm3_launch(&g, tiles, splits, a_km, b_km, drop, s);
+    TVAE_LAUNCH_CHECK("tvae_gemm");
+    return TVAE_OK;
+  }
+  dim3 grid(tiles, 1, splits);
   if (BK == 16) launch0<16>(g, grid, s, a_km, b_km, aligned, bf16, drop);
   else launch0<32>(g, grid, s, a_km, b_km, aligned, bf16, drop);
   TVAE_LAUNCH_CHECK("tvae_gemm");

@@ -1,0 +1,143 @@
+// Pieces shared by the GEMM kernels of libtvae_hip.so: argument block, tile constants, fused epilogue.
+#pragma once
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+constexpr int FLAG_VEC_EPILOGUE = 1 << 20;   // internal: float4 epilogue through LDS (set by the host wrapper)
+constexpr int EPILOGUE_LDS_FLOATS = 4 * 32 * 68;   // what gemm_epilogue needs of the kernel's LDS
+
+struct GemmArgs {
+  const float* A; const float* B; float* C; const float* bias; const float* res;
+  int lda, ldb, ldc, ldr, M, N, K;
+  float alpha; int flags;
+  const uint32_t* rng; uint32_t site; float p;
+  int k_per_split;
+  float* a_rowsum;   // A_KMAJOR only: a_rowsum[m] += sum_k A(m,k) (bias gradient fused into wgrad)
+};
+
+
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (id % 8 shares an L2),
+// so give each XCD a CONTIGUOUS run of tiles -- the column tiles that re-read one A row panel then
+// hit the same L2 instead of fetching the panel once per XCD.  (Bijective for any grid size;
+// placement is a speed matter only.)
+__device__ inline int xcd_tile_id() {
+  const int nwg = gridDim.x, id = blockIdx.x, q = nwg >> 3, rr = nwg & 7, xcd = id & 7;
+  return (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (id >> 3);
+}
+
+// Epilogue of a 128x128 tile held as 2x2 MFMA 32x32 accumulators per wave (4 waves as 2x2):
+// alpha, bias, ReLU / ReLU-mask, dropout, residual, accumulate -- or split-K atomics.  EB = row
+// segments in flight per lane in the vector path (register budget).  `lds` is the kernel's staging
+// memory (>= EPILOGUE_LDS_FLOATS floats); every wave must be past its last read of it.
+template <int EB>
+__device__ inline void gemm_epilogue(const GemmArgs& g, floatx16 (&acc)[2][2], float* lds, int m0, int n0,
+                                     bool sync_first) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, hh = lane >> 5;
+  const bool do_rowsum = sync_first;
+  // ---- epilogue ----------------------------------------------------------------------------
+  const bool relu = g.flags & TVAE_GEMM_RELU, accum = g.flags & TVAE_GEMM_ACCUM;
+  const bool splitk = g.flags & TVAE_GEMM_SPLITK, relumask = g.flags & 64;
+  DropCfg de = drop_cfg((g.flags & TVAE_GEMM_A_DROPMASK) ? nullptr : g.rng, g.site, g.p);
+  const bool lead = (blockIdx.z == 0);
+  if (g.flags & FLAG_VEC_EPILOGUE) {
+    // Row-per-lane accumulator stores are issue-bound (64 dword stores per lane).  Turn the wave's
+    // 64x64 tile through its own LDS slab instead and leave as 16 float4 per lane: 16 lanes cover
+    // one 256-byte row segment, residual / saved-activation reads are float4 too.
+    if (do_rowsum) __syncthreads();
+    constexpr int ES = 68;
+    float* T = lds + wave * (32 * ES);
+    const int c = (lane & 15) * 4;
+    const int gcol = n0 + wn * 64 + c;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.bias && gcol < g.N) bv = *reinterpret_cast<const float4*>(g.bias + gcol);
+    const float* __restrict__ aux = g.res;      // residual or saved activation; must not alias C
+    const bool need_aux = (aux != nullptr);
+    const bool col_ok = gcol < g.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {               // 32 rows per pass (LDS ops of one wave stay in order)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) T[crow(q, hh) * ES + 32 * j + r] = acc[i][j][q];
+      for (int it0 = 0; it0 < 8; it0 += EB) {
+        // batch of EB row segments: issue every global read first, then compute, then store
+        float4 m[EB], old[EB], v[EB];
+        bool ok[EB];
+        size_t coff[EB];
+#pragma unroll
+        for (int u = 0; u < EB; ++u) {
+          const int rl = (it0 + u) * 4 + (lane >> 4);
+          const int grow = m0 + wm * 64 + 32 * i + rl;
+          ok[u] = col_ok && grow < g.M;
+          coff[u] = (size_t)(ok[u] ? grow : 0) * g.ldc + (col_ok ? gcol : 0);
+          v[u] = *reinterpret_cast<const float4*>(&T[rl * ES + c]);
+          m[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          old[u] = m[u];
+          if (need_aux) m[u] = *reinterpret_cast<const float4*>(aux + (size_t)(ok[u] ? grow : 0) * g.ldr + (col_ok ? gcol : 0));
+          if (accum) old[u] = *reinterpret_cast<const float4*>(g.C + coff[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < EB; ++u) {
+          const int grow = m0 + wm * 64 + 32 * i + (it0 + u) * 4 + (lane >> 4);
+          float o[4] = {v[u].x * g.alpha + bv.x, v[u].y * g.alpha + bv.y, v[u].z * g.alpha + bv.z, v[u].w * g.alpha + bv.w};
+          const float mm[4] = {m[u].x, m[u].y, m[u].z, m[u].w};
+          if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+          }
+          if (relumask) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = mm[e] > 0.f ? o[e] : 0.f;
+          } else {
+            if (de.on) {
+              float ks[4];
+              drop_scale4(de, (uint32_t)grow * (uint32_t)g.N + (uint32_t)gcol, ks);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] *= ks[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += mm[e];      // zero when there is no residual
+          }
+          if (ok[u])
+            *reinterpret_cast<float4*>(g.C + coff[u]) =
+                make_float4(o[0] + old[u].x, o[1] + old[u].y, o[2] + old[u].z, o[3] + old[u].w);
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int col = n0 + wn * 64 + 32 * j + r;
+      if (col >= g.N) continue;
+      float bv = (g.bias && lead) ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        int row = m0 + wm * 64 + 32 * i + crow(q, hh);
+        if (row >= g.M) continue;
+        float v = acc[i][j][q] * g.alpha + bv;
+        if (splitk) {
+          atomicAdd(&g.C[(size_t)row * g.ldc + col], v);
+          continue;
+        }
+        if (relu) v = fmaxf(v, 0.f);
+        if (relumask) {
+          // backward of relu(+dropout): pass the gradient where the saved activation is > 0
+          v = (g.res[(size_t)row * g.ldr + col] > 0.f) ? v : 0.f;
+        } else {
+          v *= drop_scale(de, (uint32_t)row * (uint32_t)g.N + (uint32_t)col);
+          if (g.res) v += g.res[(size_t)row * g.ldr + col];
+        }
+        float* dst = &g.C[(size_t)row * g.ldc + col];
+        *dst = accum ? (*dst + v) : v;
+      }
+    }
+}
+
+}  // namespace

@@ -7,23 +7,28 @@ TransVAE hot path runs in libtvae_hip.so; nothing here falls back to ATen math.
 import ctypes as C
 import math
 
+import os
+
 import torch
 
 from . import _lib
-from ._lib import (F32, BF16, GEMM_RELU, GEMM_ACCUM, GEMM_A_KMAJOR, GEMM_B_KMAJOR, GEMM_SPLITK,
+from ._lib import (F32, BF16, F32X3, GEMM_RELU, GEMM_ACCUM, GEMM_A_KMAJOR, GEMM_B_KMAJOR, GEMM_SPLITK,
                    GEMM_A_DROPMASK, GEMM_RELUMASK, call)
 
 # ----------------------------------------------------------------------------- configuration
-_state = {"dtype": F32, "site": 0}
+_DTYPES = {"fp32": F32, "f32": F32, "f32x3": F32X3, "bf16": BF16}
+# TVAE_COMPUTE_DTYPE picks the GEMM arithmetic at import (default: exact fp32 MFMA)
+_state = {"dtype": _DTYPES[os.environ.get("TVAE_COMPUTE_DTYPE", "fp32")], "site": 0}
 
 
 def set_compute_dtype(name):
-    """'fp32' (exact, v_mfma_f32_32x32x2_f32) or 'bf16' (bf16 operands, fp32 accumulate)."""
-    _state["dtype"] = {"fp32": F32, "f32": F32, "bf16": BF16}[name]
+    """GEMM arithmetic: 'fp32' (exact, v_mfma_f32_32x32x2_f32), 'f32x3' (fp32-accurate: six bf16 MFMAs
+    on exact 3-way bf16 splits of the operands) or 'bf16' (operands rounded to bf16, fp32 accumulate)."""
+    _state["dtype"] = _DTYPES[name]
 
 
 def compute_dtype():
-    return "bf16" if _state["dtype"] == BF16 else "fp32"
+    return {F32: "fp32", BF16: "bf16", F32X3: "f32x3"}[_state["dtype"]]
 
 
 def next_site():

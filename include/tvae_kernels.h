@@ -54,6 +54,7 @@ extern "C" {
 #define TVAE_GEMM_B_KMAJOR 8    /* B(k,n) = B[k*ldb + n]  (default B[n*ldb + k], i.e. nn.Linear weight) */
 #define TVAE_GEMM_SPLITK 16     /* split K over grid.z, fp32 atomicAdd into C (C must be initialised) */
 #define TVAE_GEMM_RELUMASK 64   /* v = residual[m,n] > 0 ? v : 0 (`residual` is the saved activation, not added) */
+#define TVAE_GEMM_B_SPLIT3 128  /* dtype F32X3 only: B points at bf16 planes written by tvae_split3, ldb = 3*Kb in bf16 elements */
 #define TVAE_GEMM_A_DROPMASK 32 /* multiply A(m,k) by the dropout keep-scale of (rng, site, m*K+k): dgrad/wgrad of a dropped-out output */
 
 const char* tvae_last_error(void);
@@ -74,6 +75,16 @@ int tvae_gemm(const float* A, int lda, const float* B, int ldb, float* C, int ld
               int M, int N, int K, const float* bias, const float* residual, int ldr,
               float alpha, int flags, const uint32_t* rng, uint32_t site, float p_drop,
               float* a_rowsum, int dtype, void* stream);
+
+/*
+ * Three-way bf16 split of an fp32 matrix w (rows x cols, row stride ldw) for the F32X3 arithmetic:
+ * w = hi + mid + lo exactly to 2^-26, each a bf16.  out_n (rows, 3*cols): row r holds, for every group
+ * of 8 consecutive columns, the 8 hi, the 8 mid and the 8 lo values back to back (cols % 8 == 0);
+ * out_t (cols, 3*rows): the same for w^T (rows % 8 == 0).  Either may be NULL.  Lets tvae_gemm take an nn.Linear weight
+ * (forward: out_n; data gradient: out_t) as a pre-split B operand (TVAE_GEMM_B_SPLIT3), so that the
+ * kernel only splits the activation operand.  Weights change once per optimizer step.
+ */
+int tvae_split3(const float* w, int ldw, uint16_t* out_n, uint16_t* out_t, int rows, int cols, void* stream);
 
 /* out[n] (+)= sum_m X[m*ld + n] (* dropout keep-scale if rng): bias gradients. */
 int tvae_colsum(const float* X, int ld, float* out, int M, int N, int accumulate,

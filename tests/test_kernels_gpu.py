@@ -414,8 +414,9 @@ def test_sublayer_functions_match_oracle():
 
 
 # ---- fp32-accurate GEMM on the bf16 matrix cores (dtype f32x3) -------------------------------------
+@pytest.mark.parametrize("presplit", [False, True])
 @pytest.mark.parametrize("M,N,K", [(777, 256, 256), (1500, 1024, 256), (640, 256, 1024), (300, 260, 2304), (130, 132, 40)])
-def test_gemm_f32x3_is_as_accurate_as_fp32(M, N, K):
+def test_gemm_f32x3_is_as_accurate_as_fp32(M, N, K, presplit):
     """Every GEMM role (forward with bias/ReLU/residual, data gradient, weight gradient with the fused
     bias gradient) in 3xbf16-split arithmetic against an fp64 product: the error must be at the level
     of the exact-fp32 kernel's (both are printed), far from bf16's 2e-3."""
@@ -423,6 +424,8 @@ def test_gemm_f32x3_is_as_accurate_as_fp32(M, N, K):
     torch.manual_seed(M + N + K)
     x = torch.randn(M, K, device=dev())
     w = torch.randn(N, K, device=dev()) * 0.05
+    if presplit:            # an nn.Parameter weight is split once (tvae_split3) and reaches the kernel as bf16 planes
+        w = torch.nn.Parameter(w, requires_grad=False)
     b = torch.randn(N, device=dev())
     res = torch.randn(M, N, device=dev())
     dy = torch.randn(M, N, device=dev())

@@ -11,8 +11,9 @@ def err(y, ref):
 
 torch.manual_seed(0)
 for (M, N, K) in [(4096, 256, 256), (4096, 1024, 256), (2048, 256, 1024), (1000, 260, 2304)]:
-    x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") * 0.05; b = torch.randn(N, device="cuda")
+    x = torch.randn(M, K, device="cuda"); w = torch.nn.Parameter(torch.randn(N, K, device="cuda") * 0.05); b = torch.randn(N, device="cuda")
     dy = torch.randn(M, N, device="cuda")
+    torch.set_grad_enabled(False)
     ref_f = x.double() @ w.double().t() + b.double()
     ref_d = dy.double() @ w.double()
     ref_w = dy.double().t() @ x.double()

@@ -24,7 +24,7 @@ def main():
     M = 63500
     rng = ops.rng_state(torch.device("cuda", 0))
     for (N, K) in [(1024, 256), (256, 1024), (256, 256), (768, 256), (512, 256)]:
-        x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) * 0.05; b = torch.zeros(N, device=dev)
+        x = torch.randn(M, K, device=dev); w = torch.nn.Parameter(torch.randn(N, K, device=dev) * 0.05); b = torch.zeros(N, device=dev)
         y = torch.empty(M, N, device=dev); res = torch.randn(M, N, device=dev); dy = torch.randn(M, N, device=dev)
         fl = 2.0 * M * N * K
         tag = "M%d N%d K%d" % (M, N, K)

@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""One GEMM shape, a few launches, for rocprofv3 --pmc passes: python pmc_shape.py <dtype> <N> <K> [nt|nn|tn]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from transvae_amd import ops
+dt, N, K = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+kind = sys.argv[4] if len(sys.argv) > 4 else "nt"
+ops.set_compute_dtype(dt)
+M = 63500
+x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") * 0.05; b = torch.zeros(N, device="cuda")
+y = torch.empty(M, N, device="cuda"); dy = torch.randn(M, N, device="cuda")
+for _ in range(6):
+    if kind == "nt": ops.linear_fwd(x, w, b, out=y)
+    elif kind == "nn": ops.linear_dgrad(dy, w)
+    else: ops.linear_wgrad(dy, x)
+torch.cuda.synchronize()

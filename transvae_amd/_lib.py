@@ -15,12 +15,14 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtvae_hip.so")
 
 F32, BF16, F32X3 = 0, 1, 2
 GEMM_RELU, GEMM_ACCUM, GEMM_A_KMAJOR, GEMM_B_KMAJOR, GEMM_SPLITK, GEMM_A_DROPMASK, GEMM_RELUMASK = 1, 2, 4, 8, 16, 32, 64
+GEMM_B_SPLIT3 = 128
 
 _vp, _i, _f, _u = C.c_void_p, C.c_int, C.c_float, C.c_uint32
 
 # name -> argtypes; every function returns int (0 = ok) except the two string getters.
 SIGNATURES = {
     "tvae_gemm": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _f, _i, _vp, _u, _f, _vp, _i, _vp],
+    "tvae_split3": [_vp, _i, _vp, _vp, _i, _i, _vp],
     "tvae_colsum": [_vp, _i, _vp, _i, _i, _i, _vp, _u, _f, _vp],
     "tvae_layernorm_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "tvae_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],

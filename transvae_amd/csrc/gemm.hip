@@ -330,7 +330,8 @@ int tile_depth(bool bf16, int tiles, bool splitk) {
 
 }  // namespace
 
-void tvae_gemm3_launch(const void* gp, int tiles, int splits, bool a_km, bool b_km, bool drop, hipStream_t s);   // gemm3.hip
+void tvae_gemm3_launch(const void* gp, int tiles, int splits, bool a_km, bool b_km, bool drop, bool b_split,
+                       hipStream_t s);   // gemm3.hip
 
 extern "C" int tvae_gemm(const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                          int M, int N, int K, const float* bias, const float* residual, int ldr,
@@ -368,7 +369,16 @@ extern "C" int tvae_gemm(const float* A, int lda, const float* B, int ldb, float
   const bool bf16 = dtype == TVAE_BF16;
   const bool drop = (flags & TVAE_GEMM_A_DROPMASK) && rng && p_drop > 0.f;
   // split-bf16 kernel: aligned operands only; a k-major A with the A-side dropout mask stays on the fp32 kernel
-  const bool x3 = dtype == TVAE_F32X3 && aligned && !(a_km && drop);
+  const bool b_split = flags & TVAE_GEMM_B_SPLIT3;
+  if (b_split) {
+    // B holds the bf16 planes written by tvae_split3 (per row: groups of 8 hi, 8 mid, 8 lo), ldb = 3 * Kb elements
+    TVAE_CHECK(dtype == TVAE_F32X3 && !b_km && !(flags & TVAE_GEMM_SPLITK) && !(a_km && drop), TVAE_E_SHAPE,
+               "tvae_gemm: B_SPLIT3 needs dtype F32X3, an n-major B and no split-K");
+    TVAE_CHECK(ldb % 24 == 0 && ldb / 3 >= K && K % 8 == 0 && aligned16(B) && aligned16(A) && lda % 4 == 0 &&
+                   (a_km ? M % 4 == 0 : true),
+               TVAE_E_SHAPE, "tvae_gemm: B_SPLIT3 needs K %% 8 == 0, ldb = 3*Kb with Kb %% 8 == 0, aligned operands");
+  }
+  const bool x3 = dtype == TVAE_F32X3 && (b_split || (aligned && !(a_km && drop)));
   int tiles = cdiv(M, BM) * cdiv(N, BN);
   const int BK = x3 ? 32 : tile_depth(bf16, tiles, flags & TVAE_GEMM_SPLITK);
   int splits = 1;
@@ -387,7 +397,7 @@ extern "C" int tvae_gemm(const float* A, int lda, const float* B, int ldb, float
   }
   hipStream_t s = (hipStream_t)stream;
   if (x3) {
-    tvae_gemm3_launch(&g, tiles, splits, a_km, b_km, drop, s);
+    tvae_gemm3_launch(&g, tiles, splits, a_km, b_km, drop, b_split, s);
     TVAE_LAUNCH_CHECK("tvae_gemm");
     return TVAE_OK;
   }

@@ -60,11 +60,14 @@ __device__ inline void load8(Stage8& s, const float* __restrict__ P, int ld, int
   }
 }
 
+// `inside` (workgroup-uniform): every row of the tile and every k of the step exist -- no masking
 template <bool KM, bool DROP>
-__device__ inline void fix8(Stage8& s, int row0, int nrows, int k0, int kend, int tid, const DropCfg& dc, int dropK) {
+__device__ inline void fix8(Stage8& s, int row0, int nrows, int k0, int kend, int tid, const DropCfg& dc, int dropK,
+                            bool inside = false) {
+  if (!DROP && inside) return;
   const int row = KM ? (tid & 127) : (tid >> 1), kh = KM ? (tid >> 7) * 8 : (tid & 1) * 8;
   const int gr = row0 + row;
-  const bool rok = gr < nrows;
+  const bool rok = inside || gr < nrows;
   float ks[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
   if (DROP) {       // k-contiguous A only: the 8 elements are two hash groups of the dropped-out tensor
     float a[4], b[4];
@@ -75,7 +78,7 @@ __device__ inline void fix8(Stage8& s, int row0, int nrows, int k0, int kend, in
     for (int e = 0; e < 4; ++e) { ks[e] = a[e]; ks[4 + e] = b[e]; }
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) s.v[j] = (rok && k0 + kh + j < kend) ? s.v[j] * ks[j] : 0.f;
+  for (int j = 0; j < 8; ++j) s.v[j] = (rok && (inside || k0 + kh + j < kend)) ? s.v[j] * ks[j] : 0.f;
 }
 
 __device__ inline uint32_t pack_bf16(float a, float b) {
@@ -112,7 +115,34 @@ __device__ inline void store_planes(const Split8& o, unsigned short* __restrict_
   *reinterpret_cast<uint4*>(dst + 2 * PLANE) = make_uint4(o.l[0], o.l[1], o.l[2], o.l[3]);
 }
 
-template <bool A_KM, bool B_KM, bool DROP>
+// pre-split B (TVAE_GEMM_B_SPLIT3): row n of B holds, for every group of 8 consecutive k, the 8 hi, the
+// 8 mid and the 8 lo bf16 values back to back (48 contiguous bytes = what one thread stages per
+// k-step), ldb = 3 * Kb elements -- three 16-byte loads per thread and k-step, no arithmetic
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // native vector: HIP's uint4 struct went through scratch here
+struct Planes8 { u32x4 h, m, l; };
+
+__device__ inline void load_planes(Planes8& o, const unsigned short* __restrict__ B, int ldb, int n0, int N, int k0,
+                                   int kend, int tid) {
+  const int row = tid >> 1, kh = (tid & 1) * 8;
+  const int gn = n0 + row, gk = k0 + kh;
+  const bool ok = gn < N && gk < kend;
+  const unsigned short* src = B + (size_t)(ok ? gn : 0) * ldb + (ok ? gk : 0) * 3;
+  o.h = *reinterpret_cast<const u32x4*>(src);
+  o.m = *reinterpret_cast<const u32x4*>(src + 8);
+  o.l = *reinterpret_cast<const u32x4*>(src + 16);
+}
+__device__ inline void store_loaded_planes(const Planes8& o, unsigned short* __restrict__ T, int n0, int N, int k0, int kend,
+                                           int tid) {
+  const int row = tid >> 1, kh = (tid & 1) * 8;
+  const bool ok = n0 + row < N && k0 + kh < kend;
+  const u32x4 z = {0u, 0u, 0u, 0u};
+  unsigned short* dst = T + row * PITCH + kh;
+  *reinterpret_cast<u32x4*>(dst) = ok ? o.h : z;
+  *reinterpret_cast<u32x4*>(dst + PLANE) = ok ? o.m : z;
+  *reinterpret_cast<u32x4*>(dst + 2 * PLANE) = ok ? o.l : z;
+}
+
+template <bool A_KM, bool B_KM, bool DROP, bool B_SPLIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 void gemm3_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) unsigned short lds[2 * STAGE];
@@ -144,32 +174,39 @@ void gemm3_kernel(GemmArgs g) {
   // loaded-chip HBM round trip, so the loads of step kt+2 are issued before the MFMAs of step kt
   // and first touched (split + LDS store) after the MFMAs of step kt+1.
   Stage8 sa[2], sb[2];
+  Planes8 sp0, sp1;
+  const unsigned short* B16 = reinterpret_cast<const unsigned short*>(g.B);
   auto tileA = [&](int buf) { return lds + buf * STAGE; };
   auto tileB = [&](int buf) { return lds + buf * STAGE + OPER; };
-  auto issue = [&](Stage8& ra, Stage8& rb, int k0) {
+  auto issue = [&](Stage8& ra, Stage8& rb, Planes8& rp, int k0) {
     load8<A_KM>(ra, g.A, g.lda, m0, g.M, k0, kend, tid);
-    load8<B_KM>(rb, g.B, g.ldb, n0, g.N, k0, kend, tid);
+    if (B_SPLIT) load_planes(rp, B16, g.ldb, n0, g.N, k0, kend, tid);
+    else load8<B_KM>(rb, g.B, g.ldb, n0, g.N, k0, kend, tid);
   };
   // the VALU half of a commit (range masks, dropout scale, 3-way split) ...
-  auto prepare = [&](Stage8& ra, Stage8& rb, Split8& pa, Split8& pb, int k0) {
-    fix8<A_KM, DROP>(ra, m0, g.M, k0, kend, tid, dc, g.K);
-    fix8<B_KM, false>(rb, n0, g.N, k0, kend, tid, nodrop, 0);
+  const bool a_rows_in = m0 + BM <= g.M, b_rows_in = n0 + BN <= g.N;
+  auto prepare = [&](Stage8& ra, Stage8& rb, Split8& pa, Split8& pb, int k0, bool k_in = false) {
+    fix8<A_KM, DROP>(ra, m0, g.M, k0, kend, tid, dc, g.K, k_in && a_rows_in);
     if (do_rowsum) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) rs += ra.v[j];
     }
     split8(ra, pa);
-    split8(rb, pb);
+    if (!B_SPLIT) {
+      fix8<B_KM, false>(rb, n0, g.N, k0, kend, tid, nodrop, 0, k_in && b_rows_in);
+      split8(rb, pb);
+    }
   };
   // ... and its LDS half
-  auto publish = [&](const Split8& pa, const Split8& pb, int buf) {
+  auto publish = [&](const Split8& pa, const Split8& pb, const Planes8& rp, int buf, int k0) {
     store_planes<A_KM>(pa, tileA(buf), tid);
-    store_planes<B_KM>(pb, tileB(buf), tid);
+    if (B_SPLIT) store_loaded_planes(rp, tileB(buf), n0, g.N, k0, kend, tid);
+    else store_planes<B_KM>(pb, tileB(buf), tid);
   };
-  auto commit = [&](Stage8& ra, Stage8& rb, int buf, int k0) {
+  auto commit = [&](Stage8& ra, Stage8& rb, const Planes8& rp, int buf, int k0) {
     Split8 pa, pb;
     prepare(ra, rb, pa, pb, k0);
-    publish(pa, pb, buf);
+    publish(pa, pb, rp, buf, k0);
   };
   // MFMAs of one k-step from LDS buffer `buf`; with FILL the split arithmetic of the NEXT k-step
   // (whose loads landed a step ago) is issued in the gaps: an MFMA holds the SIMD's vector issue
@@ -203,9 +240,9 @@ void gemm3_kernel(GemmArgs g) {
   auto nofill = [] {};
 
   if (nkt > 0) {
-    issue(sa[0], sb[0], kbeg);
-    if (nkt > 1) issue(sa[1], sb[1], kbeg + BK3);
-    commit(sa[0], sb[0], 0, kbeg);
+    issue(sa[0], sb[0], sp0, kbeg);
+    if (nkt > 1) issue(sa[1], sb[1], sp1, kbeg + BK3);
+    commit(sa[0], sb[0], sp0, 0, kbeg);
   }
   __syncthreads();
 
@@ -216,30 +253,30 @@ void gemm3_kernel(GemmArgs g) {
   for (; kt + 3 < nkt; kt += 2) {
     {
       Split8 pa, pb;
-      issue(sa[0], sb[0], kbeg + (kt + 2) * BK3);
-      mfma_step(0, [&] { prepare(sa[1], sb[1], pa, pb, kbeg + (kt + 1) * BK3); });
+      issue(sa[0], sb[0], sp0, kbeg + (kt + 2) * BK3);
+      mfma_step(0, [&] { prepare(sa[1], sb[1], pa, pb, kbeg + (kt + 1) * BK3, true); });
       interleave();
-      publish(pa, pb, 1);
+      publish(pa, pb, sp1, 1, kbeg + (kt + 1) * BK3);
       __syncthreads();
     }
     {
       Split8 pa, pb;
-      issue(sa[1], sb[1], kbeg + (kt + 3) * BK3);
-      mfma_step(1, [&] { prepare(sa[0], sb[0], pa, pb, kbeg + (kt + 2) * BK3); });
+      issue(sa[1], sb[1], sp1, kbeg + (kt + 3) * BK3);
+      mfma_step(1, [&] { prepare(sa[0], sb[0], pa, pb, kbeg + (kt + 2) * BK3, true); });
       interleave();
-      publish(pa, pb, 0);
+      publish(pa, pb, sp0, 0, kbeg + (kt + 2) * BK3);
       __syncthreads();
     }
   }
   // tail: at most three steps, kt even
   for (; kt < nkt; kt += 2) {
-    if (kt + 2 < nkt) issue(sa[0], sb[0], kbeg + (kt + 2) * BK3);
+    if (kt + 2 < nkt) issue(sa[0], sb[0], sp0, kbeg + (kt + 2) * BK3);
     mfma_step(0, nofill);
-    if (kt + 1 < nkt) commit(sa[1], sb[1], 1, kbeg + (kt + 1) * BK3);
+    if (kt + 1 < nkt) commit(sa[1], sb[1], sp1, 1, kbeg + (kt + 1) * BK3);
     __syncthreads();
     if (kt + 1 < nkt) {
       mfma_step(1, nofill);
-      if (kt + 2 < nkt) commit(sa[0], sb[0], 0, kbeg + (kt + 2) * BK3);
+      if (kt + 2 < nkt) commit(sa[0], sb[0], sp0, 0, kbeg + (kt + 2) * BK3);
       __syncthreads();
     }
   }
@@ -253,20 +290,74 @@ void gemm3_kernel(GemmArgs g) {
   gemm_epilogue<4>(g, acc, fl, m0, n0, do_rowsum);
 }
 
-template <bool A_KM, bool B_KM>
+template <bool A_KM, bool B_KM, bool B_SPLIT>
 void launch3(const GemmArgs& g, dim3 grid, hipStream_t s, bool drop) {
-  if (drop) hipLaunchKernelGGL((gemm3_kernel<A_KM, B_KM, true>), grid, dim3(256), 0, s, g);
-  else hipLaunchKernelGGL((gemm3_kernel<A_KM, B_KM, false>), grid, dim3(256), 0, s, g);
+  if (drop) hipLaunchKernelGGL((gemm3_kernel<A_KM, B_KM, true, B_SPLIT>), grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((gemm3_kernel<A_KM, B_KM, false, B_SPLIT>), grid, dim3(256), 0, s, g);
+}
+
+// ---- tvae_split3: fp32 matrix -> hi/mid/lo bf16 planes, in the matrix's own orientation and transposed --
+// out_n[r][24*(c/8) + 8*p + c%8] and out_t[c][24*(r/8) + 8*p + r%8] (either may be null; C resp. R a
+// multiple of 8): what TVAE_GEMM_B_SPLIT3 consumes as the
+// weight operand of the forward (W) and of the data gradient (W^T).  32x32 tiles through LDS so that
+// both outputs are written along their contiguous dimension.
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ w, int ldw, unsigned short* __restrict__ out_n,
+                                                     unsigned short* __restrict__ out_t, int R, int C) {
+  __shared__ unsigned short tile[3][32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    float x = (r < R && c < C) ? w[(size_t)r * ldw + c] : 0.f;
+    const unsigned short h = __builtin_bit_cast(unsigned short, (__bf16)x);
+    const float r1 = x - __builtin_bit_cast(float, (uint32_t)h << 16);
+    const unsigned short m = __builtin_bit_cast(unsigned short, (__bf16)r1);
+    const float r2 = r1 - __builtin_bit_cast(float, (uint32_t)m << 16);
+    const unsigned short l = __builtin_bit_cast(unsigned short, (__bf16)r2);
+    tile[0][ty + 8 * i][tx] = h; tile[1][ty + 8 * i][tx] = m; tile[2][ty + 8 * i][tx] = l;
+    if (out_n && r < R && c < C) {
+      unsigned short* o = out_n + (size_t)r * (3 * C) + 24 * (c >> 3) + (c & 7);
+      o[0] = h; o[8] = m; o[16] = l;
+    }
+  }
+  __syncthreads();
+  if (out_t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = c0 + ty + 8 * i, r = r0 + tx;               // transposed: consecutive lanes -> consecutive r
+      if (r < R && c < C) {
+        unsigned short* o = out_t + (size_t)c * (3 * R) + 24 * (r >> 3) + (r & 7);
+        o[0] = tile[0][tx][ty + 8 * i]; o[8] = tile[1][tx][ty + 8 * i]; o[16] = tile[2][tx][ty + 8 * i];
+      }
+    }
+  }
 }
 
 }  // namespace
 
+extern "C" int tvae_split3(const float* w, int ldw, uint16_t* out_n, uint16_t* out_t, int rows, int cols, void* stream) {
+  TVAE_CHECK(w && (out_n || out_t), TVAE_E_NULL, "tvae_split3: null pointer");
+  TVAE_CHECK(rows > 0 && cols > 0 && ldw >= cols, TVAE_E_SHAPE, "tvae_split3: bad shape (%d x %d, ld %d)", rows, cols, ldw);
+  TVAE_CHECK((!out_n || cols % 8 == 0) && (!out_t || rows % 8 == 0), TVAE_E_SHAPE,
+             "tvae_split3: the contiguous dimension of each output must be a multiple of 8 (%d x %d)", rows, cols);
+  hipLaunchKernelGGL(split3_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0, (hipStream_t)stream, w, ldw, out_n,
+                     out_t, rows, cols);
+  TVAE_LAUNCH_CHECK("tvae_split3");
+  return TVAE_OK;
+}
+
 // called by tvae_gemm (gemm.hip) once shapes and flags are validated and `g` is filled in
-void tvae_gemm3_launch(const void* gp, int tiles, int splits, bool a_km, bool b_km, bool drop, hipStream_t s) {
+void tvae_gemm3_launch(const void* gp, int tiles, int splits, bool a_km, bool b_km, bool drop, bool b_split, hipStream_t s) {
   const GemmArgs& g = *reinterpret_cast<const GemmArgs*>(gp);
   dim3 grid(tiles, 1, splits);
-  if (!a_km && !b_km) launch3<false, false>(g, grid, s, drop);
-  else if (!a_km && b_km) launch3<false, true>(g, grid, s, drop);
-  else if (a_km && b_km) launch3<true, true>(g, grid, s, false);
-  else launch3<true, false>(g, grid, s, false);
+  if (b_split) {                       // B is pre-split, k-contiguous by construction
+    if (!a_km) launch3<false, false, true>(g, grid, s, drop);
+    else launch3<true, false, true>(g, grid, s, false);
+    return;
+  }
+  if (!a_km && !b_km) launch3<false, false, false>(g, grid, s, drop);
+  else if (!a_km && b_km) launch3<false, true, false>(g, grid, s, drop);
+  else if (a_km && b_km) launch3<true, true, false>(g, grid, s, false);
+  else launch3<true, false, false>(g, grid, s, false);
 }

@@ -12,7 +12,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (F32, BF16, F32X3, GEMM_RELU, GEMM_ACCUM, GEMM_A_KMAJOR, GEMM_B_KMAJOR, GEMM_SPLITK,
+from ._lib import (F32, BF16, F32X3, GEMM_B_SPLIT3, GEMM_RELU, GEMM_ACCUM, GEMM_A_KMAJOR, GEMM_B_KMAJOR, GEMM_SPLITK,
                    GEMM_A_DROPMASK, GEMM_RELUMASK, call)
 
 # ----------------------------------------------------------------------------- configuration
@@ -172,14 +172,55 @@ def rows_buffer(M, N, device):
     return torch.empty((M, N), device=device, dtype=torch.float32)
 
 
+# ---- pre-split weights for the f32x3 arithmetic -------------------------------------------------
+# In f32x3 mode the GEMM splits its fp32 operands into three bf16 planes on the way into LDS.  The
+# weights only change once per optimizer step, so nn.Linear weights are split ONCE per step (both
+# orientations in one launch: W for the forward, W^T for the data gradient) and handed to the kernel
+# pre-split; the kernel then only splits the activation operand.
+_weights_epoch = [0]
+
+
+def weights_changed():
+    "every cached split is stale (called after an optimizer step that wrote the weights through raw pointers)"
+    _weights_epoch[0] += 1
+
+
+def _split_weight(W):
+    """(planes of W (N, 3K), planes of W^T (K, 3N)) as int16 tensors, or None if W does not qualify."""
+    if _state["dtype"] != F32X3 or not isinstance(W, torch.nn.Parameter) or W.dim() != 2 or not W.is_contiguous():
+        return None
+    N, K = W.shape
+    if N % 8 or K % 8:
+        return None
+    # the planes live ON the parameter object: a cache keyed by address would hand a new model that
+    # reuses a freed address the old model's (possibly smaller) buffers
+    stamp = (_weights_epoch[0], W._version, W.data_ptr(), N, K)
+    hit = getattr(W, "_tvae_split3", None)
+    if hit is not None and hit[0] == stamp:
+        return hit[1], hit[2]
+    if hit is not None and hit[1].shape == (N, 3 * K) and hit[1].device == W.device:
+        wn, wt = hit[1], hit[2]                       # same shape: reuse the buffers
+    else:
+        wn = torch.empty((N, 3 * K), device=W.device, dtype=torch.int16)
+        wt = torch.empty((K, 3 * N), device=W.device, dtype=torch.int16)
+    call("tvae_split3", _p(W), K, _p(wn), _p(wt), N, K, _stream())
+    W._tvae_split3 = (stamp, wn, wt)
+    return wn, wt
+
+
 def linear_fwd(x, W, b=None, relu=False, residual=None, drop=None, out=None):
     """y[M,N] = drop(relu(x W^T + b)) + residual.  x: (M,K) contiguous rows, W: (N,K)."""
     M, K = x.shape
     N = W.shape[0]
     if out is None:
         out = torch.empty((M, N), device=x.device, dtype=torch.float32)
-    gemm(x, x.stride(0), W, W.stride(0), out, out.stride(0), M, N, K, bias=b, residual=residual,
-         ldr=0 if residual is None else residual.stride(0), flags=GEMM_RELU if relu else 0, drop=drop)
+    flags = GEMM_RELU if relu else 0
+    sp = _split_weight(W) if x.stride(0) % 4 == 0 else None
+    Bm, ldb = W, W.stride(0)
+    if sp is not None:
+        Bm, ldb, flags = sp[0], 3 * K, flags | GEMM_B_SPLIT3
+    gemm(x, x.stride(0), Bm, ldb, out, out.stride(0), M, N, K, bias=b, residual=residual,
+         ldr=0 if residual is None else residual.stride(0), flags=flags, drop=drop)
     return out
 
 
@@ -189,12 +230,17 @@ def linear_dgrad(dy, W, out=None, accumulate=False, relumask=None, alpha=1.0, a_
     K = W.shape[1]
     if out is None:
         out = torch.empty((M, K), device=dy.device, dtype=torch.float32)
-    flags = GEMM_B_KMAJOR | (GEMM_ACCUM if accumulate else 0)
+    flags = GEMM_ACCUM if accumulate else 0
     if a_drop is not None:
         flags |= GEMM_A_DROPMASK
     if relumask is not None:
         flags |= GEMM_RELUMASK
-    gemm(dy, dy.stride(0), W, W.stride(0), out, out.stride(0), M, K, N, residual=relumask,
+    sp = _split_weight(W) if dy.stride(0) % 4 == 0 else None
+    if sp is not None:                     # W^T pre-split: the contraction index (out features) is contiguous
+        Bm, ldb, flags = sp[1], 3 * N, flags | GEMM_B_SPLIT3
+    else:
+        Bm, ldb, flags = W, W.stride(0), flags | GEMM_B_KMAJOR
+    gemm(dy, dy.stride(0), Bm, ldb, out, out.stride(0), M, K, N, residual=relumask,
          ldr=0 if relumask is None else relumask.stride(0), alpha=alpha, flags=flags, drop=a_drop)
     return out
 
@@ -367,7 +413,8 @@ class LinearFn(torch.autograd.Function):
         dy2 = _c(dy).view(-1, W.shape[0])
         if ctx.relu:
             dy2 = relu_mask(dy2, y)
-        dx = linear_dgrad(dy2, W).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        # the parameter object itself (not the unpacked saved tensor) carries the pre-split planes of f32x3 mode
+        dx = linear_dgrad(dy2, ctx.P[0]).view(ctx.xshape) if ctx.needs_input_grad[0] else None
         dW, db = linear_wgrad(dy2, x2, want_bias=ctx.has_bias, W=ctx.P[0], b=ctx.P[1])
         return dx, dW, db, None
 
@@ -471,8 +518,9 @@ class AttnSublayerFn(torch.autograd.Function):
         B, h, Lq, Lk, dk, spec, drop_attn, drop_res, eps, cross = ctx.meta
         d = h * dk
         dy2 = _c(dy).view(-1, d)
-        do = linear_dgrad(dy2, Wo, a_drop=drop_res)
         pa, pb, pWq, pbq, pWk, pbk, pWv, pbv, pWo, pbo = ctx.P
+        Wq, Wk, Wv, Wo = pWq, pWk, pWv, pWo       # the parameter objects carry the pre-split planes of f32x3 mode
+        do = linear_dgrad(dy2, Wo, a_drop=drop_res)
         dWo, dbo = linear_wgrad(dy2, o, a_drop=drop_res, W=pWo, b=pbo)
         dq, dkk, dv = attn_bwd(q, k, v, o, do, lse, B, h, Lq, Lk, dk, spec, drop_attn)
         kv_in = memv if cross else n
@@ -516,6 +564,7 @@ class FFNSublayerFn(torch.autograd.Function):
         drop_ff, drop_res, eps, shp = ctx.meta
         dy2 = _c(dy).view(x2.shape)
         pa, pb, pW1, pb1, pW2, pb2 = ctx.P
+        W1, W2 = pW1, pW2                          # the parameter objects carry the pre-split planes of f32x3 mode
         dW2, db2 = linear_wgrad(dy2, hmid, a_drop=drop_res, W=pW2, b=pb2)
         # hmid = keepscale * relu(pre): hmid > 0 <=> kept and pre > 0, so one mask + one scale
         sc = 1.0 / (1.0 - drop_ff.p) if drop_ff is not None else 1.0
@@ -805,6 +854,7 @@ class FusedAdam:
         call("tvae_adam_multi", _p(ptrs), _p(self.sizes), _p(self.chunk_tensor), _p(self.chunk_start),
              len(self.params), self.n_chunks, _p(self.hyper), self.betas[0], self.betas[1], self.eps,
              int(zero_grad), _stream())
+        weights_changed()
 
 
 class ResidualDropoutFn(torch.autograd.Function):

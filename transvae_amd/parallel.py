@@ -105,6 +105,7 @@ class DataParallel:
         # parameters start identical on every rank
         for p in vae.model.parameters():
             _broadcast(p.data, src=0)
+        ops.weights_changed()                # written through .data: invalidate the pre-split copies
         self._set_grad_scale(1.0 / self.world if reduce == "mean" else 1.0)
 
     def _set_grad_scale(self, s):

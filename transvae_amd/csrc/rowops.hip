@@ -334,6 +334,31 @@ __global__ __launch_bounds__(256) void residual_dropout_kernel(const float* __re
   }
 }
 
+// float4 form of the above for N % 4 == 0 and 16-byte aligned buffers: one hash group per float4
+__global__ __launch_bounds__(256) void residual_dropout_vec_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                                   float* __restrict__ out, int rows, int N, int res_rows,
+                                                                   int pre_add, const uint32_t* rng, uint32_t site, float p) {
+  DropCfg dc = drop_cfg(rng, site, p);
+  const size_t total4 = (size_t)rows * N / 4;
+  for (size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x; i4 < total4; i4 += (size_t)gridDim.x * 256) {
+    const size_t i = i4 * 4;
+    float ks[4];
+    drop_scale4(dc, (uint32_t)i, ks);
+    const float4 v = *reinterpret_cast<const float4*>(x + i);
+    float4 o;
+    if (pre_add) {
+      const size_t row = i / N, c = i % N;
+      const float4 t = *reinterpret_cast<const float4*>(res + (row % res_rows) * N + c);
+      o = make_float4((v.x + t.x) * ks[0], (v.y + t.y) * ks[1], (v.z + t.z) * ks[2], (v.w + t.w) * ks[3]);
+    } else {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (res) t = *reinterpret_cast<const float4*>(res + i);
+      o = make_float4(t.x + v.x * ks[0], t.y + v.y * ks[1], t.z + v.z * ks[2], t.w + v.w * ks[3]);
+    }
+    *reinterpret_cast<float4*>(out + i) = o;
+  }
+}
+
 __global__ void rng_advance_kernel(uint32_t* rng) {
   if (threadIdx.x == 0 && blockIdx.x == 0) rng[1] += 1;   // vector store path (global_store_dword)
 }
@@ -520,8 +545,12 @@ extern "C" int tvae_residual_dropout(const float* x, const float* res, float* ou
   TVAE_CHECK(x && out && rows > 0 && N > 0, TVAE_E_NULL, "tvae_residual_dropout: bad arguments");
   TVAE_CHECK(!pre_add || (res && res_rows > 0), TVAE_E_NULL, "tvae_residual_dropout: pre_add needs a table");
   TVAE_CHECK((long)rows * N < (1L << 32), TVAE_E_SHAPE, "tvae_residual_dropout: index space exceeds 32 bits");
-  hipLaunchKernelGGL(residual_dropout_kernel, dim3(grid_for((size_t)rows * N)), dim3(256), 0, (hipStream_t)stream, x, res,
-                     out, rows, N, res_rows, pre_add, rng, site, p_drop);
+  if (N % 4 == 0 && aligned16(x) && aligned16(out) && (!res || aligned16(res)))
+    hipLaunchKernelGGL(residual_dropout_vec_kernel, dim3(grid_for((size_t)rows * N / 4)), dim3(256), 0, (hipStream_t)stream,
+                       x, res, out, rows, N, res_rows, pre_add, rng, site, p_drop);
+  else
+    hipLaunchKernelGGL(residual_dropout_kernel, dim3(grid_for((size_t)rows * N)), dim3(256), 0, (hipStream_t)stream, x, res,
+                       out, rows, N, res_rows, pre_add, rng, site, p_drop);
   TVAE_LAUNCH_CHECK("tvae_residual_dropout");
   return TVAE_OK;
 }

@@ -520,8 +520,9 @@ class AttnSublayerFn(torch.autograd.Function):
         dy2 = _c(dy).view(-1, d)
         pa, pb, pWq, pbq, pWk, pbk, pWv, pbv, pWo, pbo = ctx.P
         Wq, Wk, Wv, Wo = pWq, pWk, pWv, pWo       # the parameter objects carry the pre-split planes of f32x3 mode
-        do = linear_dgrad(dy2, Wo, a_drop=drop_res)
-        dWo, dbo = linear_wgrad(dy2, o, a_drop=drop_res, W=pWo, b=pbo)
+        dym, a_drop = masked_grad(dy2, drop_res)
+        do = linear_dgrad(dym, Wo, a_drop=a_drop)
+        dWo, dbo = linear_wgrad(dym, o, a_drop=a_drop, W=pWo, b=pbo)
         dq, dkk, dv = attn_bwd(q, k, v, o, do, lse, B, h, Lq, Lk, dk, spec, drop_attn)
         kv_in = memv if cross else n
         dWq, dbq = linear_wgrad(dq, n, W=pWq, b=pbq)
@@ -565,10 +566,11 @@ class FFNSublayerFn(torch.autograd.Function):
         dy2 = _c(dy).view(x2.shape)
         pa, pb, pW1, pb1, pW2, pb2 = ctx.P
         W1, W2 = pW1, pW2                          # the parameter objects carry the pre-split planes of f32x3 mode
-        dW2, db2 = linear_wgrad(dy2, hmid, a_drop=drop_res, W=pW2, b=pb2)
+        dym, a_drop = masked_grad(dy2, drop_res)
+        dW2, db2 = linear_wgrad(dym, hmid, a_drop=a_drop, W=pW2, b=pb2)
         # hmid = keepscale * relu(pre): hmid > 0 <=> kept and pre > 0, so one mask + one scale
         sc = 1.0 / (1.0 - drop_ff.p) if drop_ff is not None else 1.0
-        dh = linear_dgrad(dy2, W2, relumask=hmid, alpha=sc, a_drop=drop_res, out=rows_buffer(*hmid.shape, hmid.device))
+        dh = linear_dgrad(dym, W2, relumask=hmid, alpha=sc, a_drop=a_drop, out=rows_buffer(*hmid.shape, hmid.device))
         dW1, db1 = linear_wgrad(dh, n, W=pW1, b=pb1)
         dn = linear_dgrad(dh, W1)
         dx, da, db = layernorm_bwd(x2, ln_a, dn, add_to=dy2, eps=eps, a_param=pa, b_param=pb)
@@ -803,6 +805,19 @@ class LossFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------- Adam
+def masked_grad(dy2, drop):
+    """(gradient operand, a_drop) for the two GEMMs that consume the gradient of a dropped-out
+    output.  fp32 / bf16 kernels regenerate the keep-mask while staging (a_drop); the f32x3 kernel
+    stages a k-major operand one row at a time, across the mask's hash groups, so there the mask is
+    applied once by an elementwise pass and both GEMMs read the product."""
+    if drop is None or _state["dtype"] != F32X3:
+        return dy2, drop
+    out = torch.empty_like(dy2)
+    r, s, p = _drop_args(drop)
+    call("tvae_residual_dropout", _p(dy2), None, _p(out), dy2.shape[0], dy2.shape[1], 0, 0, r, s, p, _stream())
+    return out, None
+
+
 class FusedAdam:
     """One-launch Adam over a list of (param, grad, exp_avg, exp_avg_sq) tensors."""
     CHUNK = 4096

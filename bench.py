@@ -42,7 +42,7 @@ def time_gemm(M, N, K, dtype_name, iters=20):
     """Average duration (s) of the dominant kernel on one representative launch shape."""
     from transvae_amd import ops
     x = torch.randn(M, K, device="cuda")
-    w = torch.randn(N, K, device="cuda") * 0.05
+    w = torch.nn.Parameter(torch.randn(N, K, device="cuda") * 0.05, requires_grad=False)   # a weight, as in the model
     b = torch.zeros(N, device="cuda")
     out = ops.rows_buffer(M, N, "cuda")              # the padded-row buffer the model itself allocates
     for _ in range(3):
@@ -214,22 +214,32 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel: the MFMA GEMM on the FFN w_1 launch shape -----------
         M, N, K = args.batch * 127, 1024, 256        # the whole batch goes through in one pass
-        tg = time_gemm(M, N, K, args.dtype)
-        flops = 2.0 * M * N * K
-        ach = flops / tg / 1e12
-        # HBM bytes per launch of this kernel and shape, from separate rocprofv3 --pmc passes
-        # (tools/pmc_traffic.sh -> profiles/r1_gemm_pmc.json); None when no such measurement exists
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r1_gemm_pmc.json")
-        if args.dtype == "fp32" and os.path.exists(pmc):
-            rec = json.load(open(pmc))
-            if rec.get("shape") == [M, N, K]:
-                traffic = rec["traffic_bytes_per_launch"]
-        out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                           "frac": ach / PEAK_TFLOPS[args.dtype], "traffic": traffic,
-                           "algorithmic_bytes": 4.0 * (M * K + N * K + N + M * N),
-                           "kernel": "gemm_kernel (x[%d,%d] @ W[%d,%d]^T + bias, ReLU)" % (M, K, N, K),
-                           "launch_us": tg * 1e6, "flop_per_launch": flops}
+
+        def roofline(mode):
+            ops.set_compute_dtype(mode)
+            tg = time_gemm(M, N, K, mode)
+            flops = 2.0 * M * N * K
+            ach = flops / tg / 1e12
+            # HBM bytes per launch of this kernel and shape, from separate rocprofv3 --pmc passes
+            # (tools/pmc_traffic.sh -> profiles/r1_gemm_pmc_<mode>.json); None when no such measurement exists
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "r1_gemm_pmc_%s.json" % mode)
+            if os.path.exists(pmc):
+                rec = json.load(open(pmc))
+                if rec.get("shape") == [M, N, K]:
+                    traffic = rec["traffic_bytes_per_launch"]
+            kern = {"fp32": "gemm_kernel (v_mfma_f32_32x32x2_f32)", "bf16": "gemm_kernel (v_mfma_f32_32x32x16_bf16)",
+                    "f32x3": "gemm3_kernel (6 x v_mfma_f32_32x32x16_bf16 per fp32 product block; peak = bf16 peak / 6)"}[mode]
+            return {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[mode], "unit": "TFLOP/s",
+                    "frac": ach / PEAK_TFLOPS[mode], "traffic": traffic,
+                    "algorithmic_bytes": 4.0 * (M * K + N * K + N + M * N),
+                    "kernel": "%s: x[%d,%d] @ W[%d,%d]^T + bias, ReLU" % (kern, M, K, N, K),
+                    "launch_us": tg * 1e6, "flop_per_launch": flops}
+
+        out["roofline"] = roofline(args.dtype)
+        if not args.no_extra_modes and args.dtype != "f32x3":
+            out["roofline_f32x3"] = roofline("f32x3")
+        ops.set_compute_dtype(args.dtype)
         if not args.no_cpu_baseline and world == 1:
             threads = min(16, os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(threads)

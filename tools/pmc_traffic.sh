@@ -5,6 +5,9 @@
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp || exit 1
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$R/gpurun_out/pmc_fetch" -- python3 "$R/tools/pmc_gemm.py" > "$R/gpurun_out/pmc_fetch.log" 2>&1 || exit 1
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$R/gpurun_out/pmc_write" -- python3 "$R/tools/pmc_gemm.py" > "$R/gpurun_out/pmc_write.log" 2>&1 || exit 1
+for DT in fp32 f32x3; do
+  rm -rf "$R/gpurun_out/pmc_fetch_$DT" "$R/gpurun_out/pmc_write_$DT"
+  timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$R/gpurun_out/pmc_fetch_$DT" -- python3 "$R/tools/pmc_gemm.py" $DT > "$R/gpurun_out/pmc_fetch_$DT.log" 2>&1 || exit 1
+  timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$R/gpurun_out/pmc_write_$DT" -- python3 "$R/tools/pmc_gemm.py" $DT > "$R/gpurun_out/pmc_write_$DT.log" 2>&1 || exit 1
+done
 cd "$R" && python3 tools/pmc_summarise.py

@@ -56,7 +56,7 @@ def time_gemm(M, N, K, dtype_name, iters=20):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def cpu_baseline(threads, n_mols=100, timed=2):
+def cpu_baseline(threads, n_mols=100, timed=5):
     """The oracle's chunk (fwd + loss + bwd, dropout on like scripts/train.py) on host cores."""
     import numpy as np
     from oracle import tvae_oracle as O
@@ -81,7 +81,7 @@ def cpu_baseline(threads, n_mols=100, timed=2):
                       "(1 warm-up + %d timed, %.2f s each)" % (timed, n_mols, timed, t)}
 
 
-def cpu_decode_baseline(threads, n=4):
+def cpu_decode_baseline(threads, n=8):
     from oracle import tvae_oracle as O
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import oracle_params

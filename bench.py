@@ -113,10 +113,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
+    # TVAE_BENCH_REHEARSE=1: every rank on cuda:0 over gloo -- a functional rehearsal of the N > 1 path on a
+    # one-GPU box (RCCL refuses two ranks on one device); the numbers of such a run mean nothing
+    rehearse = os.environ.get("TVAE_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl")
+        dist.init_process_group("gloo" if rehearse else "nccl")
     dev = torch.device("cuda", local)
 
     from transvae_amd import ops, synth
@@ -141,6 +146,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def max_over_ranks(t):
+        tmax = torch.tensor([t], dtype=torch.float64, device="cpu" if rehearse else dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item())
+
     def timed(n_warm, n_steps):
         for _ in range(n_warm):
             step()
@@ -151,9 +161,7 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
-            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt = float(tmax.item())
+            dt = max_over_ranks(dt)
         return dt, tab
 
     dt, table = timed(args.warmup, args.steps)
@@ -202,11 +210,12 @@ def main():
         fence()
         td = time.perf_counter() - t0
         if world > 1:
-            tmax = torch.tensor([td], device=dev, dtype=torch.float64)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            td = float(tmax.item())
-            gathered = [torch.empty_like(ids, dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
-            dist.gather(ids.to(torch.uint8), gathered, dst=0)          # the one exchange: final token ids
+            td = max_over_ranks(td)
+            small = ids.to(torch.uint8)                                # vocabulary of 26: one byte per token
+            if rehearse:
+                small = small.cpu()
+            gathered = [torch.empty_like(small) for _ in range(world)] if rank == 0 else None
+            dist.gather(small, gathered, dst=0)                        # the one exchange: final token ids
         out["decode_mols_per_s"] = world * args.decode_n / td
         out["decode_batch_per_gpu"] = args.decode_n
         out["decode_algorithmic_tflops"] = world * args.decode_n * FLOP_PER_MOL_DECODE / td / 1e12

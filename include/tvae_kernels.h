@@ -42,6 +42,12 @@ extern "C" {
 #define TVAE_E_DTYPE (-2)
 #define TVAE_E_LAUNCH (-3)  /* hipGetLastError() after the launch was not hipSuccess */
 #define TVAE_E_NULL (-4)
+#define TVAE_E_DATA (-5)    /* tvae_encode_smiles: an input row cannot be encoded (see TVAE_TOK_*) */
+
+/* why a SMILES row was refused (tvae_encode_smiles) and what the reference raises for it */
+#define TVAE_TOK_UNMATCHED 1 /* text outside the tokenizer's forms: AssertionError, tvae_util.py:102 */
+#define TVAE_TOK_UNKNOWN 2   /* token not in CHAR_DICT: KeyError, tvae_util.py:121 */
+#define TVAE_TOK_TOO_LONG 3  /* more than max_len tokens: the row assignment fails, data.py:31 */
 
 #define TVAE_F32 0
 #define TVAE_BF16 1
@@ -258,6 +264,34 @@ int tvae_embed_step(const int64_t* ids, int ld_ids, int col, const float* lut, c
 int tvae_residual_dropout(const float* x, const float* res, float* out, int rows, int N,
                           int res_rows, int pre_add, const uint32_t* rng, uint32_t site,
                           float p_drop, void* stream);
+
+/*
+ * Data pipeline in front of the train step.
+ *
+ * tvae_encode_smiles -- HOST function, every pointer is host memory, synchronous, uses up to n_threads
+ * threads (0 = one per core, at most 16).  Does what vae_data_gen does per molecule
+ * (transvae/data.py:26-31): tokenizer() (tvae_util.py:97-103, the regex alternatives in order), then
+ * encode_smiles() (tvae_util.py:114-122: '<end>' once, then '_' up to max_len; nothing appended when the
+ * SMILES already has max_len tokens), then the leading start id.  One byte per token instead of the
+ * reference's float32.
+ *   text/offsets: string i is text[offsets[i] .. offsets[i+1]) (offsets has n+1 entries)
+ *   vocab/vocab_offsets/vocab_ids: CHAR_DICT as n_vocab byte strings and their ids (ids < 256)
+ *   out: n rows of ld >= max_len+1 bytes: [start_id, ids..., end_id, pad_id ...]
+ *   returns TVAE_E_DATA if a row cannot be encoded; bad_row / bad_code (may be NULL) name the row the
+ *   reference would have failed on first and why (TVAE_TOK_*): an untokenizable string anywhere comes before
+ *   unknown tokens and over-long rows because the reference tokenizes the whole column first.
+ *
+ * tvae_gather_batch -- DEVICE: out[b, t] = float(ids[r_b*ld_ids + t]) for t < L, out[b, L] = props[r_b]
+ * (0 when props is NULL), r_b = index[b] or first + b when index is NULL: the (B, L+1) float32 batch the
+ * reference's DataLoader collates from the float tensor of vae_data_gen (trans_models.py:176-183), built
+ * from a uint8 dataset that stays resident in HBM.  An index outside [0, n_rows) yields a row of zeros.
+ */
+int tvae_encode_smiles(const char* text, const int64_t* offsets, int64_t n, const char* vocab,
+                       const int32_t* vocab_offsets, const int32_t* vocab_ids, int n_vocab,
+                       int start_id, int end_id, int pad_id, int max_len, uint8_t* out, int64_t ld,
+                       int n_threads, int64_t* bad_row, int* bad_code);
+int tvae_gather_batch(const uint8_t* ids, int64_t ld_ids, const float* props, const int64_t* index,
+                      int64_t first, int64_t n_rows, int B, int L, float* out, int ldo, void* stream);
 
 /* bump the dropout step counter: rng[1] += 1 (one tiny launch per train step, graph-safe) */
 int tvae_rng_advance(uint32_t* rng, void* stream);

@@ -339,3 +339,44 @@ def calc_entropy(sample):
     from scipy.stats import entropy
     return np.array([entropy(np.histogram(sample[:, i], bins=1000, range=(-5., 5.),
                                           density=True)[0]) for i in range(sample.shape[1])])
+
+
+# ----------------------------------------------------------------------------- data pipeline
+import re as _re
+
+# transvae/tvae_util.py:99 -- the pattern is written there as an ordinary (non-raw) string, in which the
+# four backslashes of the `\\\\` alternative reach the regex engine as `\\`, i.e. one literal backslash
+_SMILES_PATTERN = _re.compile(
+    r"(\[[^\]]+]|Br?|Cl?|N|O|S|P|F|I|b|c|n|o|s|p|\(|\)|\.|=|#|-|\+|\\|\/|_|:|~|@|\?|>|\*|\$|\%[0-9]{2}|[0-9])")
+
+
+def tokenize(smile):
+    "tokenizer(), transvae/tvae_util.py:97-103: regex findall, then the join-back assertion"
+    tokens = _SMILES_PATTERN.findall(smile)
+    assert smile == ''.join(tokens), ("{} could not be joined".format(smile))
+    return tokens
+
+
+def encode_tokens(tokens, max_len, char_dict):
+    "encode_smiles(), transvae/tvae_util.py:114-122: '<end>' once, then '_' while the list is short of max_len"
+    tokens = list(tokens)
+    for i in range(max_len - len(tokens)):
+        tokens.append('<end>' if i == 0 else '_')
+    return [char_dict[c] for c in tokens]
+
+
+def data_rows(smiles, props, char_dict):
+    """vae_data_gen(), transvae/data.py:10-33: every string tokenized first, then per row
+    [0] + 126 ids into columns 0..126 and the property into column 127 of a float32 (N, 128) array."""
+    import numpy as np
+    toks = [tokenize(s) for s in smiles]
+    if props is None:
+        props = np.zeros(len(toks))
+    out = np.empty((len(toks), 128), dtype=np.float32)
+    for j, t in enumerate(toks):
+        row = [0] + encode_tokens(t, 126, char_dict)
+        if len(row) != 127:
+            raise RuntimeError("row %d has %d ids, the tensor row takes 127" % (j, len(row)))
+        out[j, :127] = row
+        out[j, 127] = props[j]
+    return out

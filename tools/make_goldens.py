@@ -422,11 +422,70 @@ def golden_units(tm, loss_mod, util, opt_mod):
     print("units", rec["loss_plain"], rec["loss_nan"], rec["noam_256"][:3])
 
 
+TRICKY_SMILES = [
+    # strings the reference's tokenizer / encoder accept or refuse in ways a hand-written scanner can get wrong
+    "", "C", "Cl", "Br", "B", "BrCl", "CCl", "ClC", "Clc1ccccc1Br", "C%12CC%12", "C%1", "%", "C%1a",
+    "[nH]", "[", "[]", "[]]", "[C", "c1cc[nH]c1", "C[N+](C)(C)C", "[O-]C(=O)C", "[C@@H](N)O", "[nH", "]",
+    "CX", "c1ccccc1 ", " C", "C\\C=C/C", "C\\", "H", "[H]", "C.C", "N#N", "C~C", "C:C", "C@C", "C?", "C>C",
+    "C*", "C$C", "C_C", "_", "C[nH]]", "C[[nH]]", "Cc1nc2c([nH]1)c(=O)n(C)c(=O)n2C", "\u00e9", "C\u00e9", "[\u00e9]", "C\nC",
+    "0123456789", "Si", "Se", "se", "as", "I", "F", "P", "p", "b", "(", ")", "=", "#", "-", "+", "/",
+    "C" * 125, "C" * 126, "C" * 127, "Cl" * 126, "Cl" * 127, "[nH]" * 126, "C" * 200 + "X", "X" + "C" * 200,
+]
+
+
+def golden_data(data_mod, util):
+    """The data pipeline on the reference's own example file (1000 ZINC rows) through ITS vae_data_gen, plus
+    what its tokenizer / encode_smiles / row assignment do with tricky strings, one at a time (ids or the
+    exception class) and in whole-column calls (which exception wins)."""
+    import pandas as pd
+    from transvae_amd import synth
+    rec = {}
+    smiles = pd.read_csv(os.path.join(REF, "notebooks/example_data/zinc_train_example.txt")).to_numpy()[:, 1:2]
+    props = np.random.default_rng(17).uniform(-2, 5, len(smiles))
+    for vocab in ("zinc", "pubchem"):
+        char_dict = synth.load_vocab(vocab)[0]
+        if vocab == "zinc":
+            rows = data_mod.vae_data_gen(smiles, props, char_dict).numpy()
+            rec["zinc_smiles"] = np.array([str(s) for s in smiles[:, 0]])
+            rec["zinc_props"] = props
+            rec["zinc_ids"] = rows[:, :127].astype(np.uint8)
+            rec["zinc_prop_column"] = rows[:, 127]
+            assert np.array_equal(rows[:, :127], rec["zinc_ids"])
+        outcome, ids = [], []
+        for smi in TRICKY_SMILES:
+            try:
+                row = data_mod.vae_data_gen(np.array([[smi]], dtype=object), None, char_dict).numpy()
+                outcome.append("ok")
+                ids.append(row[0, :127].astype(np.uint8))
+            except Exception as e:                      # noqa: BLE001 -- the class is the datum
+                outcome.append(type(e).__name__)
+                ids.append(np.zeros(127, dtype=np.uint8))
+        rec["tricky_outcome_" + vocab] = np.array(outcome)
+        rec["tricky_ids_" + vocab] = np.stack(ids)
+    rec["tricky_smiles"] = np.array(TRICKY_SMILES)
+    # whole-column precedence: every string is tokenized before the first is encoded
+    char_dict = synth.load_vocab("zinc")[0]
+    cols = {"unknown_then_unmatched": ["CC", "C[N+]C", "CCX", "CC"], "long_then_unknown": ["C" * 130, "C[N+]C"],
+            "unknown_and_long_in_one": ["[N+]" + "C" * 130], "long_then_unmatched": ["C" * 130, "C C"]}
+    for k, col in cols.items():
+        try:
+            data_mod.vae_data_gen(np.array(col, dtype=object)[:, None], None, char_dict)
+            rec["column_" + k] = np.array("ok")
+        except Exception as e:                          # noqa: BLE001
+            rec["column_" + k] = np.array(type(e).__name__)
+        rec["column_input_" + k] = np.array(col)
+    np.savez_compressed(os.path.join(OUT, "data.npz"), **rec)
+    print("data", rec["zinc_ids"].shape, dict(zip(*np.unique(rec["tricky_outcome_zinc"], return_counts=True))),
+          {k: str(rec["column_" + k]) for k in cols})
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     tm, loss_mod, data_mod, util, opt_mod = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "data":
+        return golden_data(data_mod, util)
     if len(sys.argv) > 1 and sys.argv[1] == "accum":
         return golden_accum(tm, loss_mod, data_mod)
     if len(sys.argv) > 1 and sys.argv[1] == "step":
@@ -440,6 +499,7 @@ def main():
     golden_decode(tm, "4x256_zinc", CONFIGS["4x256_zinc"])
     golden_attn(tm, data_mod)
     golden_units(tm, loss_mod, util, opt_mod)
+    golden_data(data_mod, util)
 
 
 if __name__ == "__main__":

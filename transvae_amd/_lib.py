@@ -17,7 +17,7 @@ F32, BF16, F32X3 = 0, 1, 2
 GEMM_RELU, GEMM_ACCUM, GEMM_A_KMAJOR, GEMM_B_KMAJOR, GEMM_SPLITK, GEMM_A_DROPMASK, GEMM_RELUMASK = 1, 2, 4, 8, 16, 32, 64
 GEMM_B_SPLIT3 = 128
 
-_vp, _i, _f, _u = C.c_void_p, C.c_int, C.c_float, C.c_uint32
+_vp, _i, _f, _u, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_int64
 
 # name -> argtypes; every function returns int (0 = ok) except the two string getters.
 SIGNATURES = {
@@ -49,6 +49,8 @@ SIGNATURES = {
     "tvae_embed_step": [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "tvae_residual_dropout": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _u, _f, _vp],
     "tvae_rng_advance": [_vp, _vp],
+    "tvae_encode_smiles": [_vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i64, _i, _vp, _vp],
+    "tvae_gather_batch": [_vp, _i64, _vp, _vp, _i64, _i64, _i, _i, _vp, _i, _vp],
 }
 
 _lib = None

@@ -85,40 +85,50 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
   for (int i = 0; i < NPL; ++i) { pa[i] = 0.f; pb[i] = 0.f; }
   const int rbeg = blockIdx.x * rows_per_wg;
   const int rend = min(rows, rbeg + rows_per_wg);
-  for (int row = rbeg + wave; row < rend; row += 4) {
-    const size_t off = (size_t)row * d + lane * NPL;
-    float v[NPL], g[NPL], res[NPL];
-    load_run<NPL>(v, x + off);
-    load_run<NPL>(g, dy + off);
-    if (add_to) load_run<NPL>(res, add_to + off);
-    float s = 0.f;
+  // two rows per trip: all six loads are in flight before the first reduction, which is what hides the HBM
+  // latency of this three-stream kernel at 8 waves per SIMD
+  for (int row0 = rbeg + wave; row0 < rend; row0 += 8) {
+    const bool two = row0 + 4 < rend;
+    const size_t off[2] = {(size_t)row0 * d + lane * NPL, (size_t)(two ? row0 + 4 : row0) * d + lane * NPL};
+    float v[2][NPL], g[2][NPL], res[2][NPL];
 #pragma unroll
-    for (int i = 0; i < NPL; ++i) s += v[i];
-    const float mean = wave_sum(s) * (1.f / d);
-    float ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) { v[i] -= mean; ss += v[i] * v[i]; }
-    const float sd = sqrtf(wave_sum(ss) * (1.f / (d - 1)));
-    const float rinv = 1.f / (sd + eps);
-    float sg = 0.f, sgx = 0.f;
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-      pb[i] += g[i];
-      pa[i] += g[i] * v[i] * rinv;
-      g[i] *= av[i];
-      sg += g[i];
-      sgx += g[i] * v[i];
+    for (int r = 0; r < 2; ++r) {
+      load_run<NPL>(v[r], x + off[r]);
+      load_run<NPL>(g[r], dy + off[r]);
+      if (add_to) load_run<NPL>(res[r], add_to + off[r]);
     }
-    sg = wave_sum(sg) * (1.f / d);
-    sgx = wave_sum(sgx);
-    const float c2 = rinv * rinv * sgx / ((d - 1) * sd);
 #pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-      float o = rinv * (g[i] - sg) - v[i] * c2;
-      if (add_to) o += res[i];
-      g[i] = o;
+    for (int r = 0; r < 2; ++r) {
+      if (r == 1 && !two) break;
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) s += v[r][i];
+      const float mean = wave_sum(s) * (1.f / d);
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) { v[r][i] -= mean; ss += v[r][i] * v[r][i]; }
+      const float sd = sqrtf(wave_sum(ss) * (1.f / (d - 1)));
+      const float rinv = 1.f / (sd + eps);
+      float sg = 0.f, sgx = 0.f;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        pb[i] += g[r][i];
+        pa[i] += g[r][i] * v[r][i] * rinv;
+        g[r][i] *= av[i];
+        sg += g[r][i];
+        sgx += g[r][i] * v[r][i];
+      }
+      sg = wave_sum(sg) * (1.f / d);
+      sgx = wave_sum(sgx);
+      const float c2 = rinv * rinv * sgx / ((d - 1) * sd);
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        float o = rinv * (g[r][i] - sg) - v[r][i] * c2;
+        if (add_to) o += res[r][i];
+        g[r][i] = o;
+      }
+      store_run<NPL>(dx + off[r], g[r]);
     }
-    store_run<NPL>(dx + off, g);
   }
 #pragma unroll
   for (int i = 0; i < NPL; ++i) { red[0][wave][lane * NPL + i] = pa[i]; red[1][wave][lane * NPL + i] = pb[i]; }

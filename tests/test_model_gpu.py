@@ -178,6 +178,41 @@ def test_greedy_decode_tokens_bit_exact(cfg_name, gemm_mode):
     assert decode_mols(ids, vae.params["ORG_DICT"]) == O.decode_mols(torch.from_numpy(g["ids"].astype(np.int64)), vae.params["ORG_DICT"])
 
 
+@pytest.mark.parametrize("gemm_mode", ["fp32", "f32x3"], indirect=True)
+def test_graph_replayed_decode_is_the_same_decode(gemm_mode):
+    """From the second call with one shape on, the 125 steps run as a replayed HIP graph: tokens must stay the
+    reference's bit for bit, for the latents it was captured with, for new latents and masks, with condition
+    tokens, and after the weights change (the capture is thrown away)."""
+    from transvae_amd import decode
+    g = load("decode_1x128_zinc")
+    vae = build("1x128_zinc")
+    z = torch.from_numpy(g["z"])
+    want = g["ids"].astype(np.int64)
+    for call in range(3):                                     # eager, capture + replay, replay
+        assert np.array_equal(vae.greedy_decode(z).cpu().numpy(), want), call
+    graphs = vae.model._tvae_decode_graphs
+    assert sum(1 for k in graphs if k[0] != "seen") == 1
+    z2 = torch.flip(z, [0])                                   # other latents through the captured graph
+    assert np.array_equal(vae.greedy_decode(z2).cpu().numpy(), want[::-1])
+    lens_e = torch.from_numpy(np.resize(g["mask_lens_explicit"], 32).astype(np.int64))
+    sm = (torch.arange(127)[None, :] < lens_e[:, None]).float().unsqueeze(1)
+    got_m = [vae.greedy_decode(z, src_mask=sm).cpu().numpy() for _ in range(2)]      # replayed: same shape
+    cond = [str(c) for c in g["cond"]]
+    got_c = [vae.greedy_decode(z[:8], condition=cond).cpu().numpy() for _ in range(3)]
+    assert all(np.array_equal(a, g["ids_cond"].astype(np.int64)) for a in got_c)
+    limit, decode.GRAPH_MAX_N = decode.GRAPH_MAX_N, 0         # plain launches for comparison
+    try:
+        assert all(np.array_equal(a, vae.greedy_decode(z, src_mask=sm).cpu().numpy()) for a in got_m)
+        with torch.no_grad():                                 # move the weights: in-place, as an optimizer would
+            vae.model.generator.proj.bias.add_(torch.linspace(-3, 3, 25, device="cuda"))
+        moved = vae.greedy_decode(z).cpu().numpy()
+    finally:
+        decode.GRAPH_MAX_N = limit
+    assert not np.array_equal(moved, want)
+    for call in range(3):
+        assert np.array_equal(vae.greedy_decode(z).cpu().numpy(), moved), call
+
+
 def test_reference_style_decode_loop_matches_cached_decoder():
     """model.decode(mem, src_mask, decoded, subsequent_mask(i)) -- the reference's own loop body --
     must agree with the KV-cached path token for token (a few steps, small batch)."""

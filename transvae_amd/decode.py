@@ -16,6 +16,14 @@ from . import ops
 from .ops import _p, _stream, call
 
 
+GRAPH_MAX_N = 2048      # latent batches up to this size are launch-bound: their step loop is replayed as a HIP graph
+
+
+def _weights_stamp(model):
+    "changes whenever a weight may have changed (in-place updates bump _version; .data writes bump the epoch)"
+    return (ops._weights_epoch[0], sum(p._version for p in model.parameters()), ops.compute_dtype())
+
+
 class GreedyDecoder:
     def __init__(self, model, h):
         self.model, self.h = model, h
@@ -26,17 +34,51 @@ class GreedyDecoder:
 
     @torch.no_grad()
     def run(self, z, key_mask, start_id, cond_ids=(), max_len=125):
-        """z (n, d_latent) on the device; key_mask (n, 127) uint8 source mask; returns (n, max_len) int64."""
+        """z (n, d_latent) on the device; key_mask (n, 127) uint8 source mask; returns (n, max_len) int64.
+
+        Small batches (n <= GRAPH_MAX_N) spend their time in ~5000 launches of tiny kernels, so from the second
+        call with the same shape on the projections + 125 steps are captured once into a HIP graph (static
+        buffers for the memory, the mask and the ids) and replayed; the arithmetic and the kernels are the same."""
+        model = self.model
+        n = z.shape[0]
+        spec = ops.MaskSpec(key_mask=key_mask)
+        mem = model.decoder.expand_memory(z, spec)            # (n, 127, d), already through decoder.norm
+        cond_ids = tuple(int(t) for t in cond_ids)
+        if n > GRAPH_MAX_N or not torch.cuda.is_available():
+            return self._steps(mem, key_mask, None, start_id, cond_ids, max_len)[:, 1:]
+        key = (n, tuple(mem.shape), cond_ids, int(start_id), max_len, z.device.index)
+        cache = model.__dict__.setdefault("_tvae_decode_graphs", {})
+        stamp = _weights_stamp(model)
+        entry = cache.get(key)
+        if entry is not None and entry["stamp"] != stamp:
+            del cache[key]                                    # weights moved since the capture: take it again
+            entry = None
+        if entry is None:
+            if cache.get(("seen", key)) != stamp:             # first call with this shape: plain launches
+                cache[("seen", key)] = stamp
+                return self._steps(mem, key_mask, None, start_id, cond_ids, max_len)[:, 1:]
+            entry = {"stamp": stamp, "mem": torch.empty_like(mem), "mask": torch.empty_like(key_mask),
+                     "ids": torch.empty((n, max_len + 1), dtype=torch.int64, device=z.device)}
+            entry["mem"].copy_(mem)
+            entry["mask"].copy_(key_mask)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._steps(entry["mem"], entry["mask"], entry["ids"], start_id, cond_ids, max_len)
+            entry["graph"] = graph
+            cache[key] = entry
+        entry["mem"].copy_(mem)
+        entry["mask"].copy_(key_mask)
+        entry["graph"].replay()
+        return entry["ids"][:, 1:].clone()
+
+    def _steps(self, mem, key_mask, ids, start_id, cond_ids, max_len):
+        "source K/V projections + max_len single-token steps; every launch goes to the current stream"
         model, h = self.model, self.h
         dec = model.decoder
-        dev = z.device
-        n = z.shape[0]
-        d = dec.size
+        dev = mem.device
+        n, Ls, d = mem.shape
         dk = d // h
         scale = 1.0 / math.sqrt(dk)
-        spec = ops.MaskSpec(key_mask=key_mask)
-        mem = dec.expand_memory(z, spec)                     # (n, 127, d), already through decoder.norm
-        Ls = mem.shape[1]
         mem2 = mem.reshape(n * Ls, d)
         T = max_len + 1
         layers = list(dec.layers)
@@ -51,7 +93,9 @@ class GreedyDecoder:
             bqkv.append(torch.cat([sl[0].bias, sl[1].bias, sl[2].bias], 0).contiguous())
         ks = [torch.empty((n, T, d), device=dev, dtype=torch.float32) for _ in layers]
         vs = [torch.empty((n, T, d), device=dev, dtype=torch.float32) for _ in layers]
-        ids = torch.full((n, T), int(start_id), dtype=torch.int64, device=dev)
+        if ids is None:
+            ids = torch.empty((n, T), dtype=torch.int64, device=dev)
+        ids.fill_(int(start_id))
         for j, t in enumerate(cond_ids):
             ids[:, j + 1] = int(t)
         emb, pos = model.tgt_embed[0], model.tgt_embed[1]
@@ -90,4 +134,4 @@ class GreedyDecoder:
                 y = self._ln(cur, dec.norm)
                 logits = ops.linear_fwd(y, gen.weight, gen.bias)
                 call("tvae_argmax_next", _p(logits), n_cls, n_cls, _p(ids), T, t + 1, n, st)
-        return ids[:, 1:]
+        return ids

@@ -51,6 +51,15 @@ def _broadcast(t, src=0):
         dist.broadcast(t, src=src)
 
 
+def mean_over_ranks(values):
+    "average a few Python floats over the ranks (epoch losses: every rank must take the same checkpoint decision)"
+    t = torch.tensor(list(values), dtype=torch.float64)
+    if not _host_staged():
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return (t / dist.get_world_size()).tolist()
+
+
 class GradArena:
     def __init__(self, model, n_buckets=4):
         params = [p for p in model.parameters() if p.requires_grad]

@@ -646,7 +646,7 @@ class VAEShell():
         rank = dist.get_rank() if world > 1 else 0
         dp = None
         if world > 1:
-            from .parallel import DataParallel
+            from .parallel import DataParallel, mean_over_ranks
             dp = DataParallel(self)
             log, save = log and rank == 0, save and rank == 0
 
@@ -713,9 +713,7 @@ class VAEShell():
             self.model.eval()
             val_loss = run(val_iter, self.eval_step, 'test', beta, False)
             if world > 1:                   # every rank must take the same best-checkpoint decision
-                both = torch.tensor([train_loss, val_loss], dtype=torch.float64, device=self._device())
-                dist.all_reduce(both)
-                train_loss, val_loss = (both / world).tolist()
+                train_loss, val_loss = mean_over_ranks([train_loss, val_loss])
             self.n_epochs += 1
             print('Epoch - {} Train - {} Val - {} KLBeta - {}'.format(self.n_epochs, train_loss, val_loss, beta))
             self.current_state['epoch'] = self.n_epochs

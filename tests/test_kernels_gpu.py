@@ -88,6 +88,24 @@ def test_gemm_bf16_mode():
     assert rel_l2(dW.cpu(), dy.float().bfloat16().double().T @ xb) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 200, 96), (77, 25, 30), (1000, 131, 36), (63, 5, 129)])
+def test_gemm_bf16_kmajor_ragged(M, N, K):
+    """bf16 mode, k-major operands (dgrad / wgrad forms: [k][row] staging + transposed LDS reads) on
+    shapes that leave partial tiles in every dimension and unaligned rows."""
+    from transvae_amd import ops, _lib
+    dy, w, x = rnd(M, N, seed=15), rnd(N, K, seed=16), rnd(M, K, seed=17)
+    bf = lambda t: t.float().bfloat16().double()
+    dxo = torch.empty((M, K), device=dev(), dtype=torch.float32)
+    ops.gemm(g32(dy), N, g32(w), K, dxo, K, M, K, N, flags=_lib.GEMM_B_KMAJOR, dtype=_lib.BF16)
+    assert rel_l2(dxo.cpu(), bf(dy) @ bf(w)) < 1e-5
+    dW = torch.zeros((N, K), device=dev(), dtype=torch.float32)
+    db = torch.zeros((N,), device=dev(), dtype=torch.float32)
+    ops.gemm(g32(dy), N, g32(x), K, dW, K, N, K, M,
+             flags=_lib.GEMM_A_KMAJOR | _lib.GEMM_B_KMAJOR | _lib.GEMM_SPLITK, dtype=_lib.BF16, a_rowsum=db)
+    assert rel_l2(dW.cpu(), bf(dy).T @ bf(x)) < 1e-5
+    assert rel_l2(db.cpu(), dy.sum(0)) < 5e-6           # the fused bias gradient sums the unrounded values
+
+
 def test_gemm_rejects_bad_shapes():
     from transvae_amd import ops, _lib
     a = torch.zeros((4, 4), device=dev())

@@ -11,7 +11,7 @@ import torch  # noqa: F401  -- FIRST: torch bundles its own libamdhip64; loading
 #                              the other runtime fail with "no ROCm-capable device is detected")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtvae_hip.so")
+LIB_PATH = os.environ.get("TVAE_LIB_PATH") or os.path.join(_HERE, "lib", "libtvae_hip.so")   # override: kernel experiments
 
 F32, BF16, F32X3 = 0, 1, 2
 GEMM_RELU, GEMM_ACCUM, GEMM_A_KMAJOR, GEMM_B_KMAJOR, GEMM_SPLITK, GEMM_A_DROPMASK, GEMM_RELUMASK = 1, 2, 4, 8, 16, 32, 64

@@ -10,6 +10,9 @@
 // four ds_read_b128 instead of 16 strided ds_read_b32.  A and B use the same permutation, so
 // the sum is unchanged (only its order, which fp32 parity tolerates at the 1e-7 level).
 //
+// (bf16 mode: k-major operands are staged [k][row] too and their fragments come from transposed
+// LDS reads, ds_read_b64_tr_b16.)
+//
 // Operands whose global layout is k-contiguous are staged as [row][k] (+4 floats of padding:
 // stride 36 floats makes the b128 fragment reads bank-conflict-free); operands whose layout
 // is m-contiguous ("k-major": weight for dgrad, both operands for wgrad) are staged as
@@ -21,6 +24,26 @@
 namespace {
 
 constexpr int LDS_KM = BM + 4;    // [k][row] stride (floats)
+// bf16 [k][row] stride (elements) of a k-major operand: 320 bytes, so the four k-rows a transposed
+// read gathers for one 32-lane half land on four different 64-byte bank spans (conflict-free)
+constexpr int BF_KM = BM + 32;
+
+// MFMA fragment (8 consecutive k of this lane's row) out of a bf16 [k][row] image: two
+// ds_read_b64_tr_b16, each a 4 (k) x 16 (rows) block per 16-lane group delivered column-major --
+// lane 4q+p of a group addresses k-row q, rows 4p..4p+3 and receives row (lane & 15), k = q' = 0..3.
+// Needs EXEC all ones (the gather crosses lanes): only called from workgroup-uniform control flow.
+typedef short short4v __attribute__((ext_vector_type(4)));
+__device__ inline bf16x8 tr_fragment(const unsigned short* T, int k0, int row0, int lane) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const unsigned short* a = T + (k0 + 8 * (g >> 1) + q) * BF_KM + row0 + 16 * (g & 1) + 4 * p;
+  typedef __attribute__((address_space(3))) short4v* lds_ptr;
+  const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)a);
+  const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a + 4 * BF_KM));
+  bf16x8 f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+  f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  return f;
+}
 
 // The k-depth of a tile is a template parameter: BK = 32 halves the barrier count, BK = 16 halves
 // LDS and the fragment registers so that three workgroups share a CU instead of two (the prologue
@@ -33,6 +56,7 @@ struct Tile {
   static constexpr int FLOATS = (BM * KC > BK * LDS_KM) ? BM * KC : BK * LDS_KM;
   static constexpr int NJ = BK / 8;                 // float4 per thread per operand tile
   static constexpr int HK = BK / 2;                 // k values owned by one lane half
+  static_assert(BK * (BM + 32) * 2 <= FLOATS * 4, "the bf16 [k][row] image must fit the fp32-sized tile");
 };
 
 __device__ inline unsigned short f2bf(float f) {
@@ -124,11 +148,9 @@ __device__ inline void stage_store_bf16(const float4 (&st)[BK / 8], unsigned sho
     if (!KM) {
       ushort4 o = make_ushort4(f2bf(st[j].x), f2bf(st[j].y), f2bf(st[j].z), f2bf(st[j].w));
       *reinterpret_cast<ushort4*>(&T[row * LDS_BF + k]) = o;
-    } else {                                // transpose on the way in: bf16 tiles are always [row][k]
-      T[(row + 0) * LDS_BF + k] = f2bf(st[j].x);
-      T[(row + 1) * LDS_BF + k] = f2bf(st[j].y);
-      T[(row + 2) * LDS_BF + k] = f2bf(st[j].z);
-      T[(row + 3) * LDS_BF + k] = f2bf(st[j].w);
+    } else {                                // k-major operands keep their orientation: [k][row], one 8-byte store
+      ushort4 o = make_ushort4(f2bf(st[j].x), f2bf(st[j].y), f2bf(st[j].z), f2bf(st[j].w));
+      *reinterpret_cast<ushort4*>(&T[k * BF_KM + row]) = o;
     }
   }
 }
@@ -241,13 +263,17 @@ void gemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-          a[i][ks] = *reinterpret_cast<const bf16x8*>(&TA[(wm * 64 + 32 * i + r) * LDS_BF + 16 * ks + 8 * hh]);
+        for (int ks = 0; ks < KS; ++ks) {
+          if (A_KM) a[i][ks] = tr_fragment(TA, 16 * ks, wm * 64 + 32 * i, lane);
+          else a[i][ks] = *reinterpret_cast<const bf16x8*>(&TA[(wm * 64 + 32 * i + r) * LDS_BF + 16 * ks + 8 * hh]);
+        }
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-          b[j][ks] = *reinterpret_cast<const bf16x8*>(&TB[(wn * 64 + 32 * j + r) * LDS_BF + 16 * ks + 8 * hh]);
+        for (int ks = 0; ks < KS; ++ks) {
+          if (B_KM) b[j][ks] = tr_fragment(TB, 16 * ks, wn * 64 + 32 * j, lane);
+          else b[j][ks] = *reinterpret_cast<const bf16x8*>(&TB[(wn * 64 + 32 * j + r) * LDS_BF + 16 * ks + 8 * hh]);
+        }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll

@@ -19,6 +19,7 @@
 // Requires 16-byte aligned operands (the host falls back to the exact-fp32 kernel otherwise, and
 // for a k-major A with the A-side dropout mask, whose hash groups run along m).
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "gemm_common.h"
 
@@ -81,11 +82,13 @@ __device__ inline void fix8(Stage8& s, int row0, int nrows, int k0, int kend, in
   for (int j = 0; j < 8; ++j) s.v[j] = (rok && (inside || k0 + kh + j < kend)) ? s.v[j] * ks[j] : 0.f;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ inline uint32_t pack_bf16(float a, float b) {
-  // the plain casts compile to v_cvt_pk_bf16_f32 (round to nearest even)
-  const unsigned short lo = __builtin_bit_cast(unsigned short, (__bf16)a);
-  const unsigned short hi = __builtin_bit_cast(unsigned short, (__bf16)b);
-  return (uint32_t)lo | ((uint32_t)hi << 16);
+  // one v_cvt_pk_bf16_f32 (round to nearest even) for the pair; two scalar casts end up as two
+  // single conversions plus a re-pack
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
 __device__ inline float bf16_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
 __device__ inline float bf16_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xFFFF0000U); }
@@ -142,6 +145,43 @@ __device__ inline void store_loaded_planes(const Planes8& o, unsigned short* __r
   *reinterpret_cast<u32x4*>(dst + 2 * PLANE) = ok ? o.l : z;
 }
 
+// ---- interior tiles ------------------------------------------------------------------------------
+// A tile whose 128 rows of both operands exist and whose k range is whole k-steps needs no range
+// test at all, and its addresses are (workgroup-uniform base, advanced on the scalar unit) + (a
+// per-thread byte offset fixed for the whole k-loop): the loads take the scalar-base form and the
+// k-step carries no address or mask arithmetic on the vector unit, which the split shares with the
+// MFMA issue.  (The general path above spends ~60 of its ~115 vector instructions per k-step there.)
+template <bool KM>
+__device__ inline uint32_t fast_off(int ld, int tid) {          // bytes
+  if (!KM) return (uint32_t)(((tid >> 1) * ld + (tid & 1) * 8) * 4);
+  return (uint32_t)((((tid >> 7) * 8) * ld + (tid & 127)) * 4);
+}
+template <bool KM>
+__device__ inline void load8_fast(Stage8& s, const float* __restrict__ base, int ld, uint32_t off) {
+  const char* b = reinterpret_cast<const char*>(base);
+  if (!KM) {
+    const float4 t0 = *reinterpret_cast<const float4*>(b + off);
+    const float4 t1 = *reinterpret_cast<const float4*>(b + off + 16);
+    s.v[0] = t0.x; s.v[1] = t0.y; s.v[2] = t0.z; s.v[3] = t0.w;
+    s.v[4] = t1.x; s.v[5] = t1.y; s.v[6] = t1.z; s.v[7] = t1.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s.v[j] = *reinterpret_cast<const float*>(b + (size_t)j * ld * 4 + off);
+  }
+}
+__device__ inline void load_planes_fast(Planes8& o, const unsigned short* __restrict__ base, uint32_t off) {
+  const char* b = reinterpret_cast<const char*>(base);
+  o.h = *reinterpret_cast<const u32x4*>(b + off);
+  o.m = *reinterpret_cast<const u32x4*>(b + off + 16);
+  o.l = *reinterpret_cast<const u32x4*>(b + off + 32);
+}
+__device__ inline void store_loaded_planes_fast(const Planes8& o, unsigned short* __restrict__ T, int tid) {
+  unsigned short* dst = T + (tid >> 1) * PITCH + (tid & 1) * 8;
+  *reinterpret_cast<u32x4*>(dst) = o.h;
+  *reinterpret_cast<u32x4*>(dst + PLANE) = o.m;
+  *reinterpret_cast<u32x4*>(dst + 2 * PLANE) = o.l;
+}
+
 template <bool A_KM, bool B_KM, bool DROP, bool B_SPLIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 void gemm3_kernel(GemmArgs g) {
@@ -178,37 +218,17 @@ void gemm3_kernel(GemmArgs g) {
   const unsigned short* B16 = reinterpret_cast<const unsigned short*>(g.B);
   auto tileA = [&](int buf) { return lds + buf * STAGE; };
   auto tileB = [&](int buf) { return lds + buf * STAGE + OPER; };
-  auto issue = [&](Stage8& ra, Stage8& rb, Planes8& rp, int k0) {
-    load8<A_KM>(ra, g.A, g.lda, m0, g.M, k0, kend, tid);
-    if (B_SPLIT) load_planes(rp, B16, g.ldb, n0, g.N, k0, kend, tid);
-    else load8<B_KM>(rb, g.B, g.ldb, n0, g.N, k0, kend, tid);
-  };
-  // the VALU half of a commit (range masks, dropout scale, 3-way split) ...
   const bool a_rows_in = m0 + BM <= g.M, b_rows_in = n0 + BN <= g.N;
-  auto prepare = [&](Stage8& ra, Stage8& rb, Split8& pa, Split8& pb, int k0, bool k_in = false) {
-    fix8<A_KM, DROP>(ra, m0, g.M, k0, kend, tid, dc, g.K, k_in && a_rows_in);
-    if (do_rowsum) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) rs += ra.v[j];
-    }
-    split8(ra, pa);
-    if (!B_SPLIT) {
-      fix8<B_KM, false>(rb, n0, g.N, k0, kend, tid, nodrop, 0, k_in && b_rows_in);
-      split8(rb, pb);
-    }
-  };
-  // ... and its LDS half
-  auto publish = [&](const Split8& pa, const Split8& pb, const Planes8& rp, int buf, int k0) {
-    store_planes<A_KM>(pa, tileA(buf), tid);
-    if (B_SPLIT) store_loaded_planes(rp, tileB(buf), n0, g.N, k0, kend, tid);
-    else store_planes<B_KM>(pb, tileB(buf), tid);
-  };
-  auto commit = [&](Stage8& ra, Stage8& rb, const Planes8& rp, int buf, int k0) {
-    Split8 pa, pb;
-    prepare(ra, rb, pa, pb, k0);
-    publish(pa, pb, rp, buf, k0);
-  };
-  // MFMAs of one k-step from LDS buffer `buf`; with FILL the split arithmetic of the NEXT k-step
+  // interior tile (workgroup-uniform): see load8_fast
+  const bool fast_tile = a_rows_in && b_rows_in && nkt > 0 && ((kend - kbeg) % BK3 == 0);
+  const uint32_t offA = fast_off<A_KM>(g.lda, tid);
+  const uint32_t offB = B_SPLIT ? (uint32_t)(((tid >> 1) * g.ldb + (tid & 1) * 24) * 2) : fast_off<B_KM>(g.ldb, tid);
+  const float* baseA = A_KM ? g.A + (size_t)kbeg * g.lda + m0 : g.A + (size_t)m0 * g.lda + kbeg;
+  const float* baseB = B_KM ? g.B + (size_t)kbeg * g.ldb + n0 : g.B + (size_t)n0 * g.ldb + kbeg;
+  const unsigned short* baseP = B16 + (size_t)n0 * g.ldb + (size_t)kbeg * 3;
+  const size_t stepA = A_KM ? (size_t)BK3 * g.lda : (size_t)BK3, stepB = B_KM ? (size_t)BK3 * g.ldb : (size_t)BK3;
+
+  // MFMAs of one k-step from LDS buffer `buf`; with a filler the split arithmetic of the NEXT k-step
   // (whose loads landed a step ago) is issued in the gaps: an MFMA holds the SIMD's vector issue
   // for 8 of its 32 cycles, so ~5 VALU instructions ride along with each for free.
   auto mfma_step = [&](int buf, auto fill) {
@@ -230,56 +250,108 @@ void gemm3_kernel(GemmArgs g) {
     TVAE_X3(2, 0) TVAE_X3(0, 2) TVAE_X3(1, 1) TVAE_X3(1, 0) TVAE_X3(0, 1) TVAE_X3(0, 0)
 #undef TVAE_X3
   };
-  auto interleave = [&]() {
-#pragma unroll
-    for (int i = 0; i < 24; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // five VALU
-    }
-  };
   auto nofill = [] {};
 
-  if (nkt > 0) {
-    issue(sa[0], sb[0], sp0, kbeg);
-    if (nkt > 1) issue(sa[1], sb[1], sp1, kbeg + BK3);
-    commit(sa[0], sb[0], sp0, 0, kbeg);
-  }
-  __syncthreads();
+  // the whole pipelined k-loop, once per addressing mode (FAST = interior tile)
+  auto k_loop = [&](auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    constexpr int VALU_PER_GAP = FAST ? 3 : 5;
+    auto issue = [&](Stage8& ra, Stage8& rb, Planes8& rp, int step) {
+      const int k0 = kbeg + step * BK3;
+      if (FAST) {
+        load8_fast<A_KM>(ra, baseA + step * stepA, g.lda, offA);
+        if (B_SPLIT) load_planes_fast(rp, baseP + (size_t)step * (3 * BK3), offB);
+        else load8_fast<B_KM>(rb, baseB + step * stepB, g.ldb, offB);
+      } else {
+        load8<A_KM>(ra, g.A, g.lda, m0, g.M, k0, kend, tid);
+        if (B_SPLIT) load_planes(rp, B16, g.ldb, n0, g.N, k0, kend, tid);
+        else load8<B_KM>(rb, g.B, g.ldb, n0, g.N, k0, kend, tid);
+      }
+    };
+    // the VALU half of a commit (range masks, dropout scale, 3-way split) ...
+    auto prepare = [&](Stage8& ra, Stage8& rb, Split8& pa, Split8& pb, int step, bool k_in = false) {
+      const int k0 = kbeg + step * BK3;
+      fix8<A_KM, DROP>(ra, m0, g.M, k0, kend, tid, dc, g.K, FAST || (k_in && a_rows_in));
+      if (do_rowsum) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rs += ra.v[j];
+      }
+      split8(ra, pa);
+      if (!B_SPLIT) {
+        fix8<B_KM, false>(rb, n0, g.N, k0, kend, tid, nodrop, 0, FAST || (k_in && b_rows_in));
+        split8(rb, pb);
+      }
+    };
+    // ... and its LDS half
+    auto publish = [&](const Split8& pa, const Split8& pb, const Planes8& rp, int buf, int step) {
+      const int k0 = kbeg + step * BK3;
+      store_planes<A_KM>(pa, tileA(buf), tid);
+      if (B_SPLIT) {
+        if (FAST) store_loaded_planes_fast(rp, tileB(buf), tid);
+        else store_loaded_planes(rp, tileB(buf), n0, g.N, k0, kend, tid);
+      } else {
+        store_planes<B_KM>(pb, tileB(buf), tid);
+      }
+    };
+    auto commit = [&](Stage8& ra, Stage8& rb, const Planes8& rp, int buf, int step) {
+      Split8 pa, pb;
+      prepare(ra, rb, pa, pb, step);
+      publish(pa, pb, rp, buf, step);
+    };
+    auto interleave = [&]() {
+#pragma unroll
+      for (int i = 0; i < 24; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_GAP, 0);   // a few VALU
+      }
+    };
 
-  // Step kt computes from LDS buffer kt&1; register set kt&1 is free (committed) and takes step
-  // kt+2.  Steady state (both a load and a commit every step), two steps per trip so that the
-  // register sets are named statically:
-  int kt = 0;
-  for (; kt + 3 < nkt; kt += 2) {
-    {
-      Split8 pa, pb;
-      issue(sa[0], sb[0], sp0, kbeg + (kt + 2) * BK3);
-      mfma_step(0, [&] { prepare(sa[1], sb[1], pa, pb, kbeg + (kt + 1) * BK3, true); });
-      interleave();
-      publish(pa, pb, sp1, 1, kbeg + (kt + 1) * BK3);
-      __syncthreads();
+    if (nkt > 0) {
+      issue(sa[0], sb[0], sp0, 0);
+      if (nkt > 1) issue(sa[1], sb[1], sp1, 1);
+      commit(sa[0], sb[0], sp0, 0, 0);
     }
-    {
-      Split8 pa, pb;
-      issue(sa[1], sb[1], sp1, kbeg + (kt + 3) * BK3);
-      mfma_step(1, [&] { prepare(sa[0], sb[0], pa, pb, kbeg + (kt + 2) * BK3, true); });
-      interleave();
-      publish(pa, pb, sp0, 0, kbeg + (kt + 2) * BK3);
-      __syncthreads();
-    }
-  }
-  // tail: at most three steps, kt even
-  for (; kt < nkt; kt += 2) {
-    if (kt + 2 < nkt) issue(sa[0], sb[0], sp0, kbeg + (kt + 2) * BK3);
-    mfma_step(0, nofill);
-    if (kt + 1 < nkt) commit(sa[1], sb[1], sp1, 1, kbeg + (kt + 1) * BK3);
     __syncthreads();
-    if (kt + 1 < nkt) {
-      mfma_step(1, nofill);
-      if (kt + 2 < nkt) commit(sa[0], sb[0], sp0, 0, kbeg + (kt + 2) * BK3);
-      __syncthreads();
+
+    // Step kt computes from LDS buffer kt&1; register set kt&1 is free (committed) and takes step
+    // kt+2.  Steady state (both a load and a commit every step), two steps per trip so that the
+    // register sets are named statically:
+    int kt = 0;
+    for (; kt + 3 < nkt; kt += 2) {
+      {
+        Split8 pa, pb;
+        issue(sa[0], sb[0], sp0, kt + 2);
+        __builtin_amdgcn_sched_barrier(0);     // the loads stay AHEAD of this step's MFMAs (two steps of flight time)
+        mfma_step(0, [&] { prepare(sa[1], sb[1], pa, pb, kt + 1, true); });
+        interleave();
+        publish(pa, pb, sp1, 1, kt + 1);
+        __syncthreads();
+      }
+      {
+        Split8 pa, pb;
+        issue(sa[1], sb[1], sp1, kt + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(1, [&] { prepare(sa[0], sb[0], pa, pb, kt + 2, true); });
+        interleave();
+        publish(pa, pb, sp0, 0, kt + 2);
+        __syncthreads();
+      }
     }
-  }
+    // tail: at most three steps, kt even
+    for (; kt < nkt; kt += 2) {
+      if (kt + 2 < nkt) issue(sa[0], sb[0], sp0, kt + 2);
+      mfma_step(0, nofill);
+      if (kt + 1 < nkt) commit(sa[1], sb[1], sp1, 1, kt + 1);
+      __syncthreads();
+      if (kt + 1 < nkt) {
+        mfma_step(1, nofill);
+        if (kt + 2 < nkt) commit(sa[0], sb[0], sp0, 0, kt + 2);
+        __syncthreads();
+      }
+    }
+  };
+  if (fast_tile) k_loop(std::true_type{});
+  else k_loop(std::false_type{});
 
   float* fl = reinterpret_cast<float*>(lds);
   if (do_rowsum) {   // every thread is past the last barrier of the k-loop: LDS is free

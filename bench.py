@@ -118,10 +118,19 @@ def main():
     rehearse = os.environ.get("TVAE_BENCH_REHEARSE") == "1"
     if rehearse:
         local = 0
+    # TVAE_BENCH_FORCE_DP=1: run the data-parallel code path (RCCL process group, gradient arena, bucketed
+    # all-reduce, final gather) even with ONE rank -- the only way to exercise the real RCCL calls on a one-GPU box
+    force_dp = os.environ.get("TVAE_BENCH_FORCE_DP") == "1"
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or force_dp
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("gloo" if rehearse else "nccl")
+        if force_dp and "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
 
     from transvae_amd import ops, synth
@@ -130,7 +139,7 @@ def main():
     vae.model.train()                                   # dropout on: what scripts/train.py runs
     ops.seed_rng(dev, 1234 + rank)
     dp = None
-    if world > 1:
+    if use_dist:
         from transvae_amd.parallel import DataParallel
         dp = DataParallel(vae)
     toks = synth.synth_tokens(args.batch, seed=100 + rank).float()
@@ -142,7 +151,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -160,7 +169,7 @@ def main():
             tab = step()
         fence()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             dt = max_over_ranks(dt)
         return dt, tab
 
@@ -209,7 +218,7 @@ def main():
         ids = vae.greedy_decode(z)
         fence()
         td = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             td = max_over_ranks(td)
             small = ids.to(torch.uint8)                                # vocabulary of 26: one byte per token
             if rehearse:
@@ -254,7 +263,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(threads)
             out["cpu_baseline_decode"] = cpu_decode_baseline(threads)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

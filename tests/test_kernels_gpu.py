@@ -190,6 +190,55 @@ def test_attention_fwd_bwd(dk, kind, Lq, Lk):
     assert rel_l2(dv.cpu(), vr.grad.reshape(-1, d)) < 5e-6
 
 
+@pytest.mark.parametrize("causal", [False, True])
+def test_attention_dead_tiles_exact(causal):
+    """Key tiles whose mask words are all zero are skipped (their weights are exact zeros).  Lengths on
+    every 32-key tile boundary, with and without the causal mask, dropout on: (a) against the oracle
+    math; (b) the values of masked keys must not matter at all -- bit-identical outputs and gradients
+    when their K / V rows are replaced by large finite junk; (c) dK / dV bit-identical to the
+    full-mask instantiation, whose dK/dV kernel skips nothing.  Molecule 0 is fully masked (uniform
+    attention over masked keys: nothing may be skipped there)."""
+    from transvae_amd import ops
+    B, h, dk, L = 8, 4, 64, 127
+    d = h * dk
+    lens = torch.tensor([0, L, 1, 3, 32, 33, 64, 97])
+    km = (torch.arange(L)[None, :] < lens[:, None])
+    q, k, v, do = rnd(B, L, d, seed=21), rnd(B, L, d, seed=22), rnd(B, L, d, seed=23), rnd(B, L, d, seed=24)
+    mask = km.unsqueeze(1) & (torch.tril(torch.ones(1, L, L, dtype=torch.bool)) if causal else torch.ones(1, L, L, dtype=torch.bool))
+    spec = ops.MaskSpec(key_mask=km.to(torch.uint8).to(dev()), causal=causal)
+    spec_full = ops.MaskSpec(full=mask.expand(B, L, L).contiguous().to(torch.uint8).to(dev()))
+    flat = lambda t: g32(t).view(-1, d)
+
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    o_ref, _ = _attn_ref(qr, kr, vr, h, mask)
+    o_ref.backward(do)
+    o, lse, _ = ops.attn_fwd(flat(q), flat(k), flat(v), B, h, L, L, dk, spec)
+    dq, dkk, dv = ops.attn_bwd(flat(q), flat(k), flat(v), o, flat(do), lse, B, h, L, L, dk, spec)
+    assert rel_l2(o.cpu(), o_ref.detach().reshape(-1, d)) < TOL
+    assert rel_l2(dq.cpu(), qr.grad.reshape(-1, d)) < 5e-6
+    assert rel_l2(dkk.cpu(), kr.grad.reshape(-1, d)) < 5e-6
+    assert rel_l2(dv.cpu(), vr.grad.reshape(-1, d)) < 5e-6
+
+    of, lsef, _ = ops.attn_fwd(flat(q), flat(k), flat(v), B, h, L, L, dk, spec_full)
+    dqf, dkf, dvf = ops.attn_bwd(flat(q), flat(k), flat(v), of, flat(do), lsef, B, h, L, L, dk, spec_full)
+    assert torch.equal(o, of) and torch.equal(dq, dqf) and torch.equal(dkk, dkf) and torch.equal(dv, dvf)
+
+    # junk in the masked keys (molecule 0 excluded: its masked keys DO carry weight), dropout on
+    ops.seed_rng(dev(), 5)
+    drop = ops.Drop(0.1, 9, ops.rng_state(dev()))
+    junk = (~km)[:, :, None].expand(B, L, d).clone()
+    junk[0] = False
+    k2, v2 = torch.where(junk, torch.full_like(k, 3.0e4), k), torch.where(junk, torch.full_like(v, -7.0e3), v)
+    oa, lsea, _ = ops.attn_fwd(flat(q), flat(k), flat(v), B, h, L, L, dk, spec, drop)
+    ob, lseb, _ = ops.attn_fwd(flat(q), flat(k2), flat(v2), B, h, L, L, dk, spec, drop)
+    assert torch.equal(oa, ob)
+    ga = ops.attn_bwd(flat(q), flat(k), flat(v), oa, flat(do), lsea, B, h, L, L, dk, spec, drop)
+    gb = ops.attn_bwd(flat(q), flat(k2), flat(v2), ob, flat(do), lseb, B, h, L, L, dk, spec, drop)
+    assert torch.equal(ga[0], gb[0])
+    live = (~junk).reshape(-1, d).to(dev())
+    assert torch.equal(ga[1] * live, gb[1] * live) and torch.equal(ga[2] * live, gb[2] * live)
+
+
 def test_attention_strided_qkv():
     """q, k, v as column blocks of one (rows, 3d) buffer (fused QKV projection layout)."""
     from transvae_amd import ops

@@ -124,6 +124,22 @@ __device__ inline uint32_t tile_mask(const AttnArgs& a, int b, int qi, int t, co
   return m;
 }
 
+// Dead tiles.  A masked score is REPLACED by -1e9, so in a row that has at least one visible key every
+// masked key gets the weight exp(-1e9 - max) = 0 exactly: a (32-query wave, 32-key tile) pair whose
+// mask words are all zero contributes exact zeros to the row sums, to P V, to dQ, dK and dV, and is
+// skipped -- same bits, less work (SMILES rows average 35 of 127 positions; the causal mask kills
+// the upper triangle).  The one case where masked keys DO carry weight is a fully masked row
+// (uniform attention over all Lk keys, greedy decode with a predicted length of 0): a wave that
+// holds such a row skips nothing.
+struct Live { bool t[4]; };
+__device__ inline Live live_tiles(const uint32_t (&mw)[4]) {
+  const bool rows_ok = __ballot((mw[0] | mw[1] | mw[2] | mw[3]) == 0U) == 0ULL;
+  Live l;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) l.t[t] = !rows_ok || __ballot(mw[t] != 0U) != 0ULL;
+  return l;
+}
+
 // key-mask words of molecule b into LDS (bit j of word t = key 32t+j unmasked and < Lk): wave 0 ballots
 __device__ inline void load_key_bits(uint32_t* key_bits, const AttnArgs& a, int b, int tid) {
   if (tid < 128) {
@@ -169,10 +185,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   DropCfg dc = drop_cfg(a.rng, a.site, a.p);
   floatx16 st[4];
   float mx = -INFINITY;
+  uint32_t mwf[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) mwf[t] = tile_mask<GENERIC>(a, b, qs, t, key_bits);
+  const Live live = live_tiles(mwf);
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
+    if (!live.t[t]) continue;
     st[t] = mma_rows_x_reg<DK>(Ks, 32 * t + r, hh, qreg);
-    const uint32_t mw = tile_mask<GENERIC>(a, b, qs, t, key_bits) >> (4 * hh);
+    const uint32_t mw = mwf[t] >> (4 * hh);
     const int nk = a.Lk - 32 * t - 4 * hh;                 // keys of this tile with in-lane offset < nk exist
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -187,13 +208,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
   float sum = 0.f;
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < 4; ++t) {
+    if (!live.t[t]) continue;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       float p = expf(st[t][i] - mx);
       st[t][i] = p;
       sum += p;
     }
+  }
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.f / sum;
   const size_t prow = ((size_t)(b * a.h + head) * a.Lq + qi);
@@ -210,6 +233,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   for (int u = 0; u < NU; ++u) oacc[u] = zero16();
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
+    if (!live.t[t]) {
+      if (GENERIC && a.p_out && qvalid) {          // the dump still gets its zeros
+        for (int i = 0; i < 16; ++i) {
+          const int key = 32 * t + crow(i, hh);
+          if (key < a.Lk) a.p_out[prow * a.Lk + key] = 0.f;
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       uint32_t keep = 0xFU;
@@ -259,6 +291,7 @@ void attn_bwd_dq_kernel(AttnArgs a) {
   DropCfg dc = drop_cfg(a.rng, a.site, a.p);
   floatx16 pt[4], dpt[4];
   uint32_t mwt[4], kwt[4];
+  Live live;
   {
     float qreg[HALF], doreg[HALF];
     {
@@ -273,7 +306,11 @@ void attn_bwd_dq_kernel(AttnArgs a) {
     }
     __syncthreads();
 #pragma unroll
+    for (int t = 0; t < 4; ++t) mwt[t] = tile_mask<GENERIC>(a, b, qs, t, key_bits);
+    live = live_tiles(mwt);
+#pragma unroll
     for (int t = 0; t < 4; ++t) {
+      if (!live.t[t]) continue;
       pt[t] = mma_rows_x_reg<DK>(Ks, 32 * t + r, hh, qreg);
       dpt[t] = mma_rows_x_reg<DK>(Vs, 32 * t + r, hh, doreg);
     }
@@ -281,7 +318,9 @@ void attn_bwd_dq_kernel(AttnArgs a) {
   float dsum = 0.f, psum = 0.f;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const uint32_t mw = tile_mask<GENERIC>(a, b, qs, t, key_bits) >> (4 * hh);
+    kwt[t] = 0U;                     // a dead tile's keep flags only ever multiply exact zeros
+    if (!live.t[t]) continue;
+    const uint32_t mw = mwt[t] >> (4 * hh);
     mwt[t] = mw;
     const int nk = qvalid ? a.Lk - 32 * t - 4 * hh : 0;
     uint32_t kw = 0;
@@ -327,6 +366,7 @@ void attn_bwd_dq_kernel(AttnArgs a) {
   for (int u = 0; u < NU; ++u) dqacc[u] = zero16();
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
+    if (!live.t[t]) continue;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       // masked entries were REPLACED by the fill value in the forward: no gradient through them
@@ -377,13 +417,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     *reinterpret_cast<uint4*>(&keep_s[tid][0]) = w;
   }
   const bool kbit = kvalid && (a.key_mask ? a.key_mask[(size_t)b * a.Lk + key] != 0 : true);
-  __syncthreads();
+  // a fully masked query row (row max == the fill value) spreads weight over masked keys: then no tile is dead
+  const bool row_full = tid < a.Lq && a.lse_in[2 * ((size_t)(b * a.h + head) * a.Lq + tid)] == MASK_FILL;
+  const bool skip_ok = !__syncthreads_or(row_full) && !(GENERIC && a.full_mask);
 
   floatx16 dkacc[NU], dvacc[NU];
 #pragma unroll
   for (int u = 0; u < NU; ++u) { dkacc[u] = zero16(); dvacc[u] = zero16(); }
 #pragma unroll 1
   for (int t = 0; t < 4; ++t) {
+    // (query tile t, this wave's key tile) is dead when no key of the wave is visible to any query of the tile
+    const int q_last = min(32 * t + 31, a.Lq - 1);
+    const bool lane_live = kbit && q_last >= 32 * t && (!a.causal || key <= q_last);
+    if (skip_ok && __ballot(lane_live) == 0ULL) continue;
     floatx16 s = mma_rows_x_reg<DK>(Qs, 32 * t + r, hh, kreg);
     floatx16 dp = mma_rows_x_reg<DK>(Gs, 32 * t + r, hh, vreg);
 #pragma unroll

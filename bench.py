@@ -56,6 +56,30 @@ def time_gemm(M, N, K, dtype_name, iters=20):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
+def roofline_of(mode, M, N, K):
+    """Roofline object of the dominant kernel (the MFMA GEMM) on one launch shape, timed live with events."""
+    from transvae_amd import ops
+    ops.set_compute_dtype(mode)
+    tg = time_gemm(M, N, K, mode)
+    flops = 2.0 * M * N * K
+    ach = flops / tg / 1e12
+    # HBM bytes per launch of this kernel and shape, from separate rocprofv3 --pmc passes
+    # (tools/pmc_traffic.sh -> profiles/r1_gemm_pmc_<mode>.json); None when no such measurement exists
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r1_gemm_pmc_%s.json" % mode)
+    if os.path.exists(pmc):
+        rec = json.load(open(pmc))
+        if rec.get("shape") == [M, N, K]:
+            traffic = rec["traffic_bytes_per_launch"]
+    kern = {"fp32": "gemm_kernel (v_mfma_f32_32x32x2_f32)", "bf16": "gemm_kernel (v_mfma_f32_32x32x16_bf16)",
+            "f32x3": "gemm3_kernel (6 x v_mfma_f32_32x32x16_bf16 per fp32 product block; peak = bf16 peak / 6)"}[mode]
+    return {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[mode], "unit": "TFLOP/s",
+            "frac": ach / PEAK_TFLOPS[mode], "traffic": traffic,
+            "algorithmic_bytes": 4.0 * (M * K + N * K + N + M * N),
+            "kernel": "%s: x[%d,%d] @ W[%d,%d]^T + bias, ReLU" % (kern, M, K, N, K),
+            "launch_us": tg * 1e6, "flop_per_launch": flops}
+
+
 def cpu_baseline(threads, n_mols=100, timed=5):
     """The oracle's chunk (fwd + loss + bwd, dropout on like scripts/train.py) on host cores."""
     import numpy as np
@@ -107,6 +131,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-extra-modes", action="store_true", help="skip the secondary timings in the other GEMM arithmetics")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="run nothing but the launches of the roofline kernel (3 warm-up + 20 timed) and print its roofline "
+                         "object: under rocprofv3 --kernel-trace --stats the profile then holds exactly these launches")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -135,6 +162,10 @@ def main():
 
     from transvae_amd import ops, synth
     ops.set_compute_dtype(args.dtype)
+    if args.roofline_only:
+        if rank == 0:
+            print(json.dumps({"roofline": roofline_of(args.dtype, args.batch * 127, 1024, 256)}), flush=True)
+        return
     vae = build_vae(batch=args.batch, chunks=args.chunks)
     vae.model.train()                                   # dropout on: what scripts/train.py runs
     ops.seed_rng(dev, 1234 + rank)
@@ -234,25 +265,7 @@ def main():
         M, N, K = args.batch * 127, 1024, 256        # the whole batch goes through in one pass
 
         def roofline(mode):
-            ops.set_compute_dtype(mode)
-            tg = time_gemm(M, N, K, mode)
-            flops = 2.0 * M * N * K
-            ach = flops / tg / 1e12
-            # HBM bytes per launch of this kernel and shape, from separate rocprofv3 --pmc passes
-            # (tools/pmc_traffic.sh -> profiles/r1_gemm_pmc_<mode>.json); None when no such measurement exists
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r1_gemm_pmc_%s.json" % mode)
-            if os.path.exists(pmc):
-                rec = json.load(open(pmc))
-                if rec.get("shape") == [M, N, K]:
-                    traffic = rec["traffic_bytes_per_launch"]
-            kern = {"fp32": "gemm_kernel (v_mfma_f32_32x32x2_f32)", "bf16": "gemm_kernel (v_mfma_f32_32x32x16_bf16)",
-                    "f32x3": "gemm3_kernel (6 x v_mfma_f32_32x32x16_bf16 per fp32 product block; peak = bf16 peak / 6)"}[mode]
-            return {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[mode], "unit": "TFLOP/s",
-                    "frac": ach / PEAK_TFLOPS[mode], "traffic": traffic,
-                    "algorithmic_bytes": 4.0 * (M * K + N * K + N + M * N),
-                    "kernel": "%s: x[%d,%d] @ W[%d,%d]^T + bias, ReLU" % (kern, M, K, N, K),
-                    "launch_us": tg * 1e6, "flop_per_launch": flops}
+            return roofline_of(mode, M, N, K)
 
         out["roofline"] = roofline(args.dtype)
         if not args.no_extra_modes and args.dtype != "f32x3":

@@ -130,6 +130,56 @@ def test_train_chunk_matches_reference_golden_and_oracle(cfg_name, gemm_mode):
     assert float(np.median(list(errs.values()))) < max(5e-6, 2.0 * float(np.median(ref_vals)))
 
 
+@pytest.mark.parametrize("gemm_mode", ["bf16"], indirect=True)
+@pytest.mark.parametrize("cfg_name", ["1x128_zinc", "4x256_zinc", "4x256_pubchem_pp"])
+def test_train_chunk_bf16_mode_within_1e_2(cfg_name, gemm_mode):
+    """bf16 mode (GEMM operands rounded to bf16, fp32 accumulation; LayerNorm, softmax, loss, attention in
+    fp32) against the reference's fp64 run on the golden inputs.  What is held to the north star's 1e-2:
+    every loss term (measured: <= 1.3e-3), the encoder outputs and the logits, and the gradient NORM of the
+    median tensor (measured 1e-3; worst tensor 2.8e-2).  What is not: the element-wise direction of a
+    gradient tensor -- rel-L2 2e-2 at the median, 0.1-0.18 for the worst (embedding rows, z_var bias):
+    forty-odd GEMMs with 2^-9 operand rounding in a row, no reference bf16 path to compare with
+    (the reference has no autocast), so the bars below are the measured level plus margin and DESIGN.md
+    section 2 states it."""
+    g = load("step_" + cfg_name)
+    vae = build(cfg_name)
+    vae.model.eval()
+    toks = torch.from_numpy(g["tokens"].astype(np.int64))
+    props, eps = torch.from_numpy(g["props"]), torch.from_numpy(g["eps"])
+    out, (x_out, mu, logvar, pred_len, prop) = run_chunk(vae, toks, props, eps, float(g["beta"]))
+    out[0].backward()
+    got = np.array([float(o.detach()) for o in out])
+    np.testing.assert_allclose(got, g["loss_f64"], rtol=1e-2, atol=1e-6)
+    assert rel_l2(mu.detach().cpu(), g["mu"]) < 1e-2
+    assert rel_l2(logvar.detach().cpu(), g["logvar"]) < 1e-2
+    assert rel_l2(pred_len.detach().cpu(), g["pred_len"]) < 1e-2
+    assert rel_l2(x_out.detach().cpu()[[0, 2, 5]], g["logits_rows"]) < 1e-2
+    named = dict(vae.model.named_parameters())
+    keys = [str(k) for k in g["grad_keys"]]
+    # gradient norms of every tensor against the reference's fp64 norms, full gradients where the golden holds them
+    nerr = {}
+    for i, k in enumerate(keys):
+        nrm = g["grad_norm_f64"][i]
+        if nrm < 1e-10:
+            continue
+        nerr[k] = abs(float(np.linalg.norm(named[k].grad.detach().cpu().double().numpy())) - nrm) / nrm
+    ferr = {}
+    for name in g.files:
+        if name.startswith("grad_full/"):
+            k = name[len("grad_full/"):]
+            if np.linalg.norm(g[name]) > 1e-10:
+                ferr[k] = rel_l2(named[k].grad.cpu(), g[name])
+    worst_n, worst_f = max(nerr, key=nerr.get), max(ferr, key=ferr.get)
+    print("bf16 [%s]: losses rel err %s; gradient-norm error median %.2e worst %.2e (%s); full-gradient rel-L2 median %.2e worst %.2e (%s)"
+          % (cfg_name, np.array2string(np.abs(got - g["loss_f64"]) / np.maximum(np.abs(g["loss_f64"]), 1e-12), precision=1),
+             float(np.median(list(nerr.values()))), nerr[worst_n], worst_n,
+             float(np.median(list(ferr.values()))), ferr[worst_f], worst_f))
+    assert float(np.median(list(nerr.values()))) < 1e-2
+    assert nerr[worst_n] < 5e-2
+    assert float(np.median(list(ferr.values()))) < 3e-2
+    assert ferr[worst_f] < 0.25
+
+
 def test_accumulation_noam_adam_matches_reference():
     g = load("accum_1x128_zinc")
     vae = build("1x128_zinc", WARMUP_STEPS=int(g["warmup"]), BATCH_CHUNKS=2, BATCH_SIZE=12)

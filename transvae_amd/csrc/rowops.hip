@@ -69,16 +69,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 }
 
 // dx_i = r*(g_i - mean(g)) - xc_i * r^2 * sum_j(g_j xc_j) / ((d-1) sd),  g = dy*a, r = 1/(sd+eps)
-// da += dy * xc * r ; db += dy.  Each workgroup walks ROWS_PER_WG rows, keeps da/db partials in
-// registers, reduces the 4 waves through LDS and issues one atomic per column.
+// da += dy * xc * r ; db += dy.  Each workgroup (up to 16 waves) walks rows_per_wg rows, keeps da/db
+// partials in registers, reduces its waves through LDS and issues one atomic per column.
 template <int NPL>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ a,
+__global__ __launch_bounds__(512) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ a,
                                                      const float* __restrict__ dy, const float* __restrict__ add_to,
                                                      float* __restrict__ dx, float* __restrict__ da,
                                                      float* __restrict__ db, int rows, int rows_per_wg, float eps) {
   constexpr int d = 64 * NPL;
-  __shared__ float red[2][4][d];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float red[2][8][d];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   float av[NPL], pa[NPL], pb[NPL];
   load_run<NPL>(av, a + lane * NPL);
 #pragma unroll
@@ -87,9 +87,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
   const int rend = min(rows, rbeg + rows_per_wg);
   // two rows per trip: all six loads are in flight before the first reduction, which is what hides the HBM
   // latency of this three-stream kernel at 8 waves per SIMD
-  for (int row0 = rbeg + wave; row0 < rend; row0 += 8) {
-    const bool two = row0 + 4 < rend;
-    const size_t off[2] = {(size_t)row0 * d + lane * NPL, (size_t)(two ? row0 + 4 : row0) * d + lane * NPL};
+  for (int row0 = rbeg + wave; row0 < rend; row0 += 2 * nw) {
+    const bool two = row0 + nw < rend;
+    const size_t off[2] = {(size_t)row0 * d + lane * NPL, (size_t)(two ? row0 + nw : row0) * d + lane * NPL};
     float v[2][NPL], g[2][NPL], res[2][NPL];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -133,9 +133,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 #pragma unroll
   for (int i = 0; i < NPL; ++i) { red[0][wave][lane * NPL + i] = pa[i]; red[1][wave][lane * NPL + i] = pb[i]; }
   __syncthreads();
-  for (int c = threadIdx.x; c < d; c += 256) {
-    float sa = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
-    float sb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    float sa = 0.f, sb = 0.f;
+    for (int w = 0; w < nw; ++w) { sa += red[0][w][c]; sb += red[1][w][c]; }
     atomicAdd(&da[c], sa);
     atomicAdd(&db[c], sb);
   }
@@ -383,6 +383,9 @@ inline int grid_for(size_t total) {
 #define LN_DISPATCH(NPL_, KERNEL, ...)                                          \
   case NPL_: hipLaunchKernelGGL((KERNEL<NPL_>), grid, dim3(256), 0, s, __VA_ARGS__); break;
 
+#define LN_DISPATCH_B(NPL_, KERNEL, ...)                                        \
+  case NPL_: hipLaunchKernelGGL((KERNEL<NPL_>), grid, block, 0, s, __VA_ARGS__); break;
+
 extern "C" int tvae_layernorm_fwd(const float* x, const float* a, const float* b, float* y, int rows, int d,
                                   float eps, void* stream) {
   TVAE_CHECK(x && a && b && y, TVAE_E_NULL, "tvae_layernorm_fwd: null pointer");
@@ -410,18 +413,22 @@ extern "C" int tvae_layernorm_bwd(const float* x, const float* a, const float* d
   TVAE_CHECK(rows > 0 && d % 64 == 0 && d >= 64 && d <= 512, TVAE_E_SHAPE,
              "tvae_layernorm_bwd: d=%d must be a multiple of 64 in [64,512], rows=%d", d, rows);
   hipStream_t s = (hipStream_t)stream;
-  int rpw = rows / 2048;          // aim at ~2048 workgroups; 4 waves walk rpw rows
-  rpw = rpw < 8 ? 8 : (rpw > 64 ? 64 : (rpw + 3) / 4 * 4);
-  dim3 grid(cdiv(rows, rpw));
+  // The column sums da, db leave every workgroup as 2*d same-address atomics, and those, not the four
+  // streams, were the kernel's limit (68 us with ~2000 workgroups of 4 waves, 47 us with the atomics
+  // removed): ~1000 workgroups of 8 waves keep the waves per CU and halve the atomics -> 51 us.
+  int rpw = (rows / 1024 + 15) / 16 * 16;
+  rpw = rpw < 16 ? 16 : (rpw > 256 ? 256 : rpw);
+  const int threads = 512;
+  dim3 grid(cdiv(rows, rpw)), block(threads);
   switch (d / 64) {
-    LN_DISPATCH(1, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
-    LN_DISPATCH(2, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
-    LN_DISPATCH(3, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
-    LN_DISPATCH(4, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
-    LN_DISPATCH(5, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
-    LN_DISPATCH(6, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
-    LN_DISPATCH(7, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
-    LN_DISPATCH(8, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
+    LN_DISPATCH_B(1, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
+    LN_DISPATCH_B(2, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
+    LN_DISPATCH_B(3, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
+    LN_DISPATCH_B(4, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
+    LN_DISPATCH_B(5, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
+    LN_DISPATCH_B(6, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
+    LN_DISPATCH_B(7, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
+    LN_DISPATCH_B(8, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
   }
   TVAE_LAUNCH_CHECK("tvae_layernorm_bwd");
   return TVAE_OK;

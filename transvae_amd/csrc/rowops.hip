@@ -197,12 +197,26 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
   for (int i = threadIdx.x; i < vocab * d; i += 256) tab[i] = 0.f;
   __syncthreads();
   const int rbeg = blockIdx.x * rows_per_wg, rend = min(rows, rbeg + rows_per_wg);
-  for (int row = rbeg; row < rend; ++row) {
-    int64_t id = ids[row];
-    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
-    for (int c = threadIdx.x; c < d; c += 256) {
-      float g = dout[(size_t)row * d + c] * drop_scale(dc, (uint32_t)row * (uint32_t)d + (uint32_t)c) * sq;
-      tab[id * d + c] += g;   // one thread per column: no intra-workgroup race
+  // one thread per column: no intra-workgroup race.  Eight rows per trip: their id and gradient loads are all
+  // issued before the first LDS add (a row at a time, every row paid a full HBM round trip: 73 us per launch)
+  for (int c = threadIdx.x; c < d; c += 256) {
+    for (int row0 = rbeg; row0 < rend; row0 += 8) {
+      int64_t id[8];
+      float g[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int row = min(row0 + u, rend - 1);
+        id[u] = ids[row];
+        g[u] = dout[(size_t)row * d + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int row = row0 + u;
+        if (row < rend) {
+          const int64_t t = id[u] < 0 ? 0 : (id[u] >= vocab ? vocab - 1 : id[u]);
+          tab[t * d + c] += g[u] * drop_scale(dc, (uint32_t)row * (uint32_t)d + (uint32_t)c) * sq;
+        }
+      }
     }
   }
   __syncthreads();

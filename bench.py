@@ -259,6 +259,23 @@ def main():
         out["decode_mols_per_s"] = world * args.decode_n / td
         out["decode_batch_per_gpu"] = args.decode_n
         out["decode_algorithmic_tflops"] = world * args.decode_n * FLOP_PER_MOL_DECODE / td / 1e12
+        if not args.no_extra_modes and args.dtype == "fp32":
+            # the same decode with the fp32-accurate 3xbf16 GEMMs (token sequences bit-identical: tests/test_model_gpu.py)
+            ops.set_compute_dtype("f32x3")
+            vae.greedy_decode(z[:64])
+            fence()
+            t0 = time.perf_counter()
+            ids3 = vae.greedy_decode(z)
+            fence()
+            t3 = time.perf_counter() - t0
+            if use_dist:
+                t3 = max_over_ranks(t3)
+            ops.set_compute_dtype(args.dtype)
+            out["decode_other_gemm_modes"] = {"f32x3": {"value": world * args.decode_n / t3, "unit": "molecules/s",
+                                                        # two fp32-accurate arithmetics round differently: among millions of
+                                                        # arg-max decisions a few near-ties (top-2 logit margin below fp32
+                                                        # resolution) fall the other way and the row diverges from there
+                                                        "rows_identical_to_fp32": float((ids3 == ids).all(dim=1).float().mean().item())}}
 
     if rank == 0:
         # ---- roofline of the dominant kernel: the MFMA GEMM on the FFN w_1 launch shape -----------

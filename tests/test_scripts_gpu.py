@@ -55,3 +55,43 @@ def test_train_sample_attention_scripts(tmp_path, monkeypatch):
     assert sa.shape == (12, 4, 4, 127, 127) and xa.shape == (12, 3, 4, 126, 127)
     np.testing.assert_allclose(sa.sum(-1), 1.0, atol=1e-4)          # every dumped row is a softmax
     np.testing.assert_allclose(xa.sum(-1), 1.0, atol=1e-4)
+
+
+CONTRACT_KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"]
+
+
+def _run_bench(*flags):
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                      # ONE JSON line on stdout, nothing else
+    return json.loads(lines[0])
+
+
+def test_bench_prints_the_contract_line():
+    """bench.py as the driver runs it (shortened): one JSON line with the contract's keys, the metric and config of
+    BASELINE.json, a roofline object for the dominant kernel and the CPU baseline."""
+    import json
+    out = _run_bench("--gpus", "1", "--steps", "2", "--warmup", "1", "--decode-n", "512", "--no-extra-modes")
+    for k in CONTRACT_KEYS:
+        assert k in out, k
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert out["metric"] == base["metric"] and out["unit"] == "tokens/s" and out["n_gpus"] == 1
+    assert out["steps"] == 2 and out["warmup"] == 1 and out["higher_is_better"] is True and out["scaling"] == "weak"
+    assert out["vs_baseline"] is None and out["data"] == "synthetic" and "workload" in out["config"]
+    assert abs(out["value"] - 500 * 126 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+    rf = out["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert 0.2 < rf["frac"] < 1.0
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "tokens/s"
+    assert out["value"] > 50 * cb["value"]              # a GPU step that is not faster than the host has fallen off the HIP path
+    assert out["decode_mols_per_s"] > 0
+
+
+def test_bench_roofline_only():
+    out = _run_bench("--roofline-only", "--dtype", "f32x3")
+    assert list(out) == ["roofline"] and "gemm3_kernel" in out["roofline"]["kernel"]

@@ -136,6 +136,16 @@ def main():
                          "object: under rocprofv3 --kernel-trace --stats the profile then holds exactly these launches")
     args = ap.parse_args()
 
+    # stdout carries ONE JSON line and nothing else: libraries that print there from native code (RCCL's version banner
+    # on communicator creation, gloo's connection notes) are sent to stderr for the whole run, and the line is written
+    # to the real stdout at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -164,7 +174,7 @@ def main():
     ops.set_compute_dtype(args.dtype)
     if args.roofline_only:
         if rank == 0:
-            print(json.dumps({"roofline": roofline_of(args.dtype, args.batch * 127, 1024, 256)}), flush=True)
+            emit({"roofline": roofline_of(args.dtype, args.batch * 127, 1024, 256)})
         return
     vae = build_vae(batch=args.batch, chunks=args.chunks)
     vae.model.train()                                   # dropout on: what scripts/train.py runs
@@ -292,7 +302,7 @@ def main():
             threads = min(16, os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(threads)
             out["cpu_baseline_decode"] = cpu_decode_baseline(threads)
-        print(json.dumps(out), flush=True)
+        emit(out)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

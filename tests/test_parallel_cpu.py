@@ -55,8 +55,8 @@ def _worker(rank, world, port, overlap, q):
         ((model(xs[2:]) - ys[2:]) ** 2).mean().backward()
         dp.finish()
     scale = dp.vae.optimizer.optimizer.grad_scale
-    q.put((rank, (dp.arena.flat * scale).clone(), [p.grad.data_ptr() for p in model.parameters()],
-           dp.arena.flat.data_ptr(), len(dp.arena.buckets)))
+    q.put((rank, (dp.arena.packed() * scale).clone(), [p.grad.data_ptr() for p in model.parameters()],
+           dp.arena.flat.data_ptr(), dp.arena.flat.numel(), len(dp.arena.buckets)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -81,10 +81,10 @@ def _run(overlap):
         ((model(xs[:2]) - ys[:2]) ** 2).mean().backward()
         ((model(xs[2:]) - ys[2:]) ** 2).mean().backward()
     ref = torch.cat([p.grad.reshape(-1) for p in reversed(list(model.parameters()))]) / 2
-    for rank, flat, ptrs, base, nb in res:
+    for rank, flat, ptrs, base, numel, nb in res:
         assert 2 <= nb <= 3
         assert torch.allclose(flat, ref, rtol=1e-5, atol=1e-7), (rank, (flat - ref).abs().max())
-        assert all(base <= p < base + flat.numel() * 4 for p in ptrs)       # every grad is an arena view
+        assert all(base <= p < base + numel * 4 and (p - base) % 256 == 0 for p in ptrs)   # every grad is an aligned arena view
     assert torch.equal(res[0][1], res[1][1])
 
 
@@ -169,7 +169,7 @@ def _mixed_worker(rank, world, port, q):
         loss.backward()
     launched_early = len(dp._launched)
     dp.finish()
-    q.put((rank, dp.arena.flat.numpy().copy(), launched_early))
+    q.put((rank, dp.arena.packed().numpy().copy(), launched_early))
     dist.barrier()
     dist.destroy_process_group()
 

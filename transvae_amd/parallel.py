@@ -61,22 +61,33 @@ def mean_over_ranks(values):
 
 
 class GradArena:
+    ALIGN = 64                      # floats
+
+    def packed(self):
+        "the gradients without the alignment padding, in arena order"
+        return torch.cat([self.flat[o:o + n] for o, n in self.slices])
+
     def __init__(self, model, n_buckets=4):
         params = [p for p in model.parameters() if p.requires_grad]
         # backward reaches parameters roughly in reverse registration order
         order = list(reversed(params))
-        total = sum(p.numel() for p in order)
+        # every slice starts on a 256-byte boundary: the weight-gradient kernels add 128-byte runs with fp32 atomics,
+        # and a slice that starts mid cache line makes every run straddle two (measured: +16 us on each such launch)
+        pad = lambda n: (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        total = sum(pad(p.numel()) for p in order)
         dev = order[0].device
         self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
         self.buckets = []           # (start, end, set(param ids))
+        self.slices = []            # (offset, numel) per parameter, in arena order
         target = (total + n_buckets - 1) // n_buckets
         off, bstart, members = 0, 0, []
         self.bucket_of = {}
         for p in order:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
+            self.slices.append((off, n))
             members.append(p)
-            off += n
+            off += pad(n)
             if off - bstart >= target or p is order[-1]:
                 bi = len(self.buckets)
                 for q in members:

@@ -80,29 +80,48 @@ def roofline_of(mode, M, N, K):
             "launch_us": tg * 1e6, "flop_per_launch": flops}
 
 
-def cpu_baseline(threads, n_mols=100, timed=5):
-    """The oracle's chunk (fwd + loss + bwd, dropout on like scripts/train.py) on host cores."""
-    import numpy as np
+def cpu_baseline(threads, batch=500, chunks=5):
+    """The oracle's train step on host cores, as SURVEY.md 8(d) asks: batch 500 = 5 chunks of 100 molecules, each
+    chunk forward + loss + backward with the gradients accumulating, then one Noam/Adam step.  Two figures: dropout
+    on (what scripts/train.py of the reference really runs; `value`) and dropout off.  Bounded sample: one untimed
+    chunk to warm the allocator and the thread pool, then ONE timed step per figure."""
     from oracle import tvae_oracle as O
     from transvae_amd import synth
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import oracle_params
     torch.set_num_threads(threads)
     P = oracle_params("4x256_zinc", torch.float32, requires_grad=True)
+    keys = [k for k in P if P[k].requires_grad]        # the two positional tables are buffers
     w = torch.tensor(synth.load_vocab("zinc")[2], dtype=torch.float32)
-    toks = synth.synth_tokens(n_mols, seed=1)
-    times = []
-    for it in range(timed + 1):
-        for v in P.values():
-            v.grad = None
-        t0 = time.perf_counter()
-        losses, _ = O.chunk_loss(P, toks, torch.zeros(n_mols), w, 0.01, p_drop=0.1, attn_drop=0.1)
-        losses[0].backward()
-        times.append(time.perf_counter() - t0)
-    t = float(np.mean(times[1:]))
-    return {"value": n_mols * 126 / t, "unit": "tokens/s", "cores": threads, "kind": "port",
-            "sample": "%d chunk(s) of %d molecules, trans4x-256 fwd+loss+bwd, dropout 0.1, fp32 torch CPU oracle "
-                      "(1 warm-up + %d timed, %.2f s each)" % (timed, n_mols, timed, t)}
+    toks = synth.synth_tokens(batch, seed=1)
+    props = torch.zeros(batch)
+    csize = batch // chunks
+    m = [torch.zeros_like(P[k]) for k in keys]
+    v = [torch.zeros_like(P[k]) for k in keys]
+
+    def step(n, p_drop, n_chunks=chunks):
+        for k in keys:
+            P[k].grad = None
+        for c in range(n_chunks):
+            sl = slice(c * csize, (c + 1) * csize)
+            losses, _ = O.chunk_loss(P, toks[sl], props[sl], w, 0.01, p_drop=p_drop, attn_drop=p_drop)
+            losses[0].backward()                      # accumulates, no 1/chunks (trans_models.py:236)
+        with torch.no_grad():
+            O.adam_step([P[k] for k in keys], [P[k].grad for k in keys], m, v, n, O.noam_rate(n, 256))
+
+    step(1, 0.1, n_chunks=1)                          # warm-up: one chunk
+    t0 = time.perf_counter()
+    step(2, 0.1)
+    t_on = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    step(3, 0.0)
+    t_off = time.perf_counter() - t0
+    return {"value": batch * 126 / t_on, "unit": "tokens/s", "cores": threads, "kind": "port",
+            "value_dropout_off": batch * 126 / t_off,
+            "sample": "one train step of trans4x-256 on %d molecules = %d chunks of %d (forward + loss + backward per chunk, "
+                      "gradients accumulated, then Noam/Adam), fp32 torch CPU oracle on %d threads; 1 warm-up chunk, then 1 "
+                      "timed step with dropout 0.1 as the reference trains (%.1f s; `value`) and 1 with dropout off (%.1f s; "
+                      "`value_dropout_off`)" % (batch, chunks, csize, threads, t_on, t_off)}
 
 
 def cpu_decode_baseline(threads, n=8):
@@ -117,6 +136,39 @@ def cpu_decode_baseline(threads, n=8):
     t = time.perf_counter() - t0
     return {"value": n / t, "unit": "molecules/s", "cores": threads, "kind": "port",
             "sample": "%d latents, reference-style full-recompute greedy loop, %.1f s" % (n, t)}
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks of this same command line (one per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) BEFORE anything in this process has touched the
+    GPU, pass rank 0's JSON line through, and fail if any rank fails.  Counting devices does not initialise the GPU."""
+    import socket
+    import subprocess
+    rehearse = os.environ.get("TVAE_BENCH_REHEARSE") == "1"
+    have = torch.cuda.device_count()
+    if have < n and not rehearse:
+        sys.stderr.write("bench.py: --gpus %d but this machine shows %d GPU(s); refusing to report a world size it did "
+                         "not run (TVAE_BENCH_REHEARSE=1 rehearses N ranks on one GPU over gloo, numbers meaningless)\n"
+                         % (n, have))
+        return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    line, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if any(codes):
+        sys.stderr.write("bench.py: rank exit codes %s\n" % codes)
+        return 1
+    sys.stdout.write(line.decode())
+    sys.stdout.flush()
+    return 0
 
 
 def main():
@@ -135,6 +187,10 @@ def main():
                     help="run nothing but the launches of the roofline kernel (3 warm-up + 20 timed) and print its roofline "
                          "object: under rocprofv3 --kernel-trace --stats the profile then holds exactly these launches")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
 
     # stdout carries ONE JSON line and nothing else: libraries that print there from native code (RCCL's version banner
     # on communicator creation, gloo's connection notes) are sent to stderr for the whole run, and the line is written
@@ -158,6 +214,9 @@ def main():
     # TVAE_BENCH_FORCE_DP=1: run the data-parallel code path (RCCL process group, gradient arena, bucketed
     # all-reduce, final gather) even with ONE rank -- the only way to exercise the real RCCL calls on a one-GPU box
     force_dp = os.environ.get("TVAE_BENCH_FORCE_DP") == "1"
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher and the flag disagree\n" % (args.gpus, world))
+        sys.exit(2)
     torch.cuda.set_device(local)
     use_dist = world > 1 or force_dp
     if use_dist:
@@ -168,6 +227,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     dev = torch.device("cuda", local)
 
     from transvae_amd import ops, synth
@@ -183,6 +243,7 @@ def main():
     if use_dist:
         from transvae_amd.parallel import DataParallel
         dp = DataParallel(vae)
+        dp.timing = True                 # GPU time the compute stream spends waiting for the bucket all-reduces
     toks = synth.synth_tokens(args.batch, seed=100 + rank).float()
     data = torch.cat([toks, torch.zeros(args.batch, 1)], 1).to(dev)     # resident in HBM
     beta = 0.01
@@ -210,11 +271,27 @@ def main():
             tab = step()
         fence()
         dt = time.perf_counter() - t0
+        mine = dt
         if use_dist:
             dt = max_over_ranks(dt)
-        return dt, tab
+        return dt, tab, mine
 
-    dt, table = timed(args.warmup, args.steps)
+    if dp is not None:
+        dp.wait_events = []
+    dt, table, dt_mine = timed(args.warmup, args.steps)
+    dp_report = None
+    if use_dist:
+        # per-rank step time and the time each rank's compute stream stood waiting in dp.finish() for its buckets
+        waits = [a.elapsed_time(b) for a, b in dp.wait_events[-args.steps:]]
+        mine = torch.tensor([1e3 * dt_mine / args.steps, sum(waits) / max(len(waits), 1)], dtype=torch.float64,
+                            device="cpu" if rehearse else dev)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        dp_report = {"ms_per_step_per_rank": [float(t[0]) for t in allr],
+                     "allreduce_wait_ms_per_step_per_rank": [float(t[1]) for t in allr],
+                     "gradient_bytes_per_step": int(dp.arena.flat.numel() * 4), "buckets": len(dp.arena.buckets),
+                     "backend": dist.get_backend()}
+        dp.timing = False
     last_loss = float(table[:, 0].mean().item())
     tokens = world * args.batch * 126 * args.steps
     value = tokens / dt
@@ -231,6 +308,7 @@ def main():
                    "global_batch": world * args.batch, "seq_len": 126,
                    "parallelism": "dp%d" % world if world > 1 else "single"},
         "final_loss": last_loss,
+        "data_parallel": dp_report,
         "train_algorithmic_tflops": world * args.batch * FLOP_PER_MOL_FWD_BWD * args.steps / dt / 1e12,
         "train_frac_of_mfma_peak": (args.batch * FLOP_PER_MOL_FWD_BWD * args.steps / dt / 1e12) / PEAK_TFLOPS[args.dtype],
     }
@@ -242,7 +320,7 @@ def main():
             if mode == args.dtype:
                 continue
             ops.set_compute_dtype(mode)
-            dto, _ = timed(2, args.steps)
+            dto, _, _ = timed(2, args.steps)
             others[mode] = {"value": tokens / dto, "unit": "tokens/s", "ms_per_step": 1e3 * dto / args.steps,
                             "parity": "fp32 tolerances (tests/test_model_gpu.py runs in this mode too)" if mode != "bf16"
                                       else "1e-2 (operands rounded to bf16)"}

@@ -221,13 +221,20 @@ int tvae_loss_fwd_bwd(const int64_t* tokens, const float* logits, int ldl, const
  *   ptrs: device array of 4*n_tensors pointers laid out [p_0..][g_0..][m_0..][v_0..]
  *   sizes: device int64[n_tensors]; chunk_tensor/chunk_start: device int32 tables, one entry
  *   per 4096-element chunk (built once by the host)
- *   hyper: device float[4] = {lr, bias_correction1, bias_correction2, grad_scale} (so a captured
- *   graph can be replayed with a new step)
+ *   beta1, beta2, eps and the four numbers below are DOUBLES: 1 - beta is formed in double before it is rounded to
+ *   the kernel's fp32 (float(0.999) is 0.99900001, and 1 - that is off by 1.3e-5 relative -- visible in the update).
+ *   lr, bias_correction1 (1 - beta1^step), bias_correction2 (1 - beta2^step), grad_scale (every gradient is
+ *   multiplied by it first: 1/world under data parallelism): BY VALUE, so that a host that queues steps ahead
+ *   of the GPU cannot overwrite the numbers of a step that has not run yet.
+ *   hyper: NULL, or device float[4] = {lr, bias_correction1, bias_correction2, grad_scale} that REPLACES the
+ *   four by-value arguments (for a captured graph that is replayed with new numbers; the caller then owns the
+ *   ordering of its writes to that buffer against the launches that read it)
  *   zero_grad != 0: g is zeroed after use (model.zero_grad(), trans_models.py:238)
  */
 int tvae_adam_multi(void* const* ptrs, const int64_t* sizes, const int32_t* chunk_tensor,
                     const int64_t* chunk_start, int n_tensors, int n_chunks,
-                    const float* hyper, float beta1, float beta2, float eps, int zero_grad,
+                    const float* hyper, double lr, double bias_correction1, double bias_correction2,
+                    double grad_scale, double beta1, double beta2, double eps, int zero_grad,
                     void* stream);
 
 /*

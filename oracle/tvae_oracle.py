@@ -93,9 +93,15 @@ def mha(P, pre, q_in, k_in, v_in, mask, h, p_drop=0.0, want_p=False):
     return linear(P, pre + ".linears.3", o)
 
 
+_FFN_TAP = [None]        # gate_margins() listens here to the hidden pre-activations of every feed-forward block
+
+
 def ffn(P, pre, x, p_drop=0.0):
     """transvae/trans_models.py:951-952."""
-    hmid = F.relu(linear(P, pre + ".w_1", x))
+    hpre = linear(P, pre + ".w_1", x)
+    if _FFN_TAP[0] is not None:
+        _FFN_TAP[0](pre, hpre)
+    hmid = F.relu(hpre)
     if p_drop > 0:
         hmid = F.dropout(hmid, p_drop)
     return linear(P, pre + ".w_2", hmid)
@@ -234,6 +240,56 @@ def chunk_loss(P, src, props, weights, beta, h=4, eps=None, eps_scale=1.0,
     losses = trans_vae_loss(src, logits, mu, logvar, true_len, pred_len, props, prop,
                             weights, beta)
     return losses, dict(logits=logits, mu=mu, logvar=logvar, pred_len=pred_len, prop=prop)
+
+
+def gate_margins(P, src, eps, h=4, eps_scale=1.0):
+    """Distance of every ReLU / MaxPool gate from its switching point, per molecule: MaxPool pairs |u - v| and the ReLU
+    input max(u, v) of the three conv layers (transvae/trans_models.py:980-983), the ReLU input of decoder.linear
+    (:852), of the three deconv layers (:1006-1009) and of the hidden layer of all seven feed-forward blocks (:952).
+    ReLU / MaxPool make the GRADIENT discontinuous there: when a margin is below an implementation's rounding error
+    on that pre-activation, two correct fp32 implementations (the reference on another BLAS included) may pick
+    different sides, and the gradients upstream differ by far more than rounding.  Run in float64; the parity tests
+    use it to tell arithmetic error from such coin flips.
+    Margins are RELATIVE to the layer's rms pre-activation over the batch (an fp32 product's error scales with the
+    size of its terms: 1.2 for conv0, 0.08 for deconv2 on the synthetic checkpoint).
+    Returns {gate name: (B,) tensor of the molecule's smallest relative margin}."""
+    m = {}
+
+    def tap(pre, hpre):
+        m["ffn:" + pre] = hpre.abs().flatten(1).min(1)[0] / hpre.pow(2).mean().sqrt()
+
+    _FFN_TAP[0] = tap
+    try:
+        with torch.no_grad():
+            tgt, src_mask, tgt_mask = make_masks(src)
+            x = embed(P, "src_embed", src)
+            for i in range(count_layers(P, "encoder.layers")):
+                x = encoder_layer(P, "encoder.layers.%d" % i, x, src_mask, h)
+            y = layer_norm(x, P["encoder.norm.a_2"], P["encoder.norm.b_2"]).permute(0, 2, 1)
+            for i in range(3):
+                pre = "encoder.conv_bottleneck.conv_layers.%d.0" % i
+                c = F.conv1d(y, P[pre + ".weight"], P[pre + ".bias"])
+                L = c.shape[-1] // 2 * 2
+                u, v = c[..., 0:L:2], c[..., 1:L:2]
+                rms = c.pow(2).mean().sqrt()
+                m["pool%d" % i] = (u - v).abs().flatten(1).min(1)[0] / rms
+                m["crelu%d" % i] = torch.maximum(u, v).abs().flatten(1).min(1)[0] / rms
+                y = F.relu(F.max_pool1d(c, 2))
+            flat = y.contiguous().view(y.size(0), -1)
+            mu, logvar = linear(P, "encoder.z_means", flat), linear(P, "encoder.z_var", flat)
+            z = mu + eps.to(mu.dtype) * eps_scale * torch.exp(0.5 * logvar)
+            d = linear(P, "decoder.linear", z)
+            m["dlin"] = d.abs().min(1)[0] / d.pow(2).mean().sqrt()
+            t = F.relu(d).view(-1, 64, 9)
+            for i, stride in enumerate((4, 3, 1)):
+                pre = "decoder.deconv_bottleneck.deconv_layers.%d.0" % i
+                c = F.conv_transpose1d(t, P[pre + ".weight"], P[pre + ".bias"], stride=stride, padding=2)
+                m["deconv%d" % i] = c.abs().flatten(1).min(1)[0] / c.pow(2).mean().sqrt()
+                t = F.relu(c)
+            decode(P, z, src_mask, tgt, tgt_mask, h)          # the feed-forward blocks of final_encodes and the decoder layers
+    finally:
+        _FFN_TAP[0] = None
+    return m
 
 
 def adam_step(params, grads, m, v, step, lr, beta1=0.9, beta2=0.98, eps=1e-9):

@@ -45,7 +45,7 @@ def train_parser():
         ('--checkpoint', _opt(None, str)),
         ('--save_name', _opt(None, str)), ('--save_freq', _opt(5, int)),
         # additions (no counterpart in the reference)
-        ('--compute_dtype', dict(default='fp32', choices=['fp32', 'bf16'], type=str)),
+        ('--compute_dtype', dict(default=None, choices=['fp32', 'f32x3', 'bf16'], type=str)),   # None: TVAE_COMPUTE_DTYPE, else fp32
     ])
 
 

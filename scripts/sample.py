@@ -10,7 +10,7 @@ import pandas as pd
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from scripts.parsers import require_transformer, sample_parser  # noqa: E402
 from transvae_amd.trans_models import TransVAE  # noqa: E402
-from transvae_amd.tvae_util import calc_entropy  # noqa: E402
+from transvae_amd.tvae_util import calc_entropy, decode_mols  # noqa: E402
 
 
 def sample(args):
@@ -21,7 +21,7 @@ def sample(args):
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
-        dist.init_process_group('nccl')
+        dist.init_process_group(os.environ.get('TVAE_DIST_BACKEND', 'nccl'))
         torch.manual_seed(torch.initial_seed() + rank)
         np.random.seed(rank)
     vae = TransVAE(load_fn=args.model_ckpt)
@@ -33,17 +33,27 @@ def sample(args):
         sample_dims = np.where(np.array(calc_entropy(mus)) > args.entropy_cutoff)[0]
         sample_mode = 'top_dims' if args.sample_mode == 'high_entropy' else 'k_dims'
 
-    mine = args.n_samples // world + (1 if rank < args.n_samples % world else 0)
-    samples = []
-    while len(samples) < mine:
-        samples.extend(vae.sample(args.n_samples_per_batch, sample_mode=sample_mode, sample_dims=sample_dims,
-                                  k=args.k, condition=condition))
+    # every rank decodes its share in batches of n_samples_per_batch (the reference's loop, :47-51, over-shoots to whole
+    # batches); what travels between ranks is ONE gather of token ids, one byte each (26-token vocabulary)
+    def n_batches(r):
+        share = args.n_samples // world + (1 if r < args.n_samples % world else 0)
+        return -(-share // args.n_samples_per_batch)
+    ids = [vae.sample(args.n_samples_per_batch, sample_mode=sample_mode, sample_dims=sample_dims, k=args.k,
+                      condition=condition, return_str=False) for _ in range(n_batches(rank))]
+    import torch
+    ids = torch.cat(ids).to(torch.uint8) if ids else torch.empty((0, vae.tgt_len), dtype=torch.uint8)
     if world > 1:
-        parts = [None] * world if rank == 0 else None
-        dist.gather_object(samples, parts, dst=0)
+        rows = [n_batches(r) * args.n_samples_per_batch for r in range(world)]
+        padded = torch.zeros((max(rows), ids.shape[1]), dtype=torch.uint8, device=ids.device)
+        padded[:ids.shape[0]] = ids
+        if dist.get_backend() == 'gloo':
+            padded = padded.cpu()
+        parts = [torch.empty_like(padded) for _ in range(world)] if rank == 0 else None
+        dist.gather(padded, parts, dst=0)
         if rank == 0:
-            samples = [s for part in parts for s in part]
+            ids = torch.cat([part[:n] for part, n in zip(parts, rows)])
         dist.destroy_process_group()
+    samples = decode_mols(ids.long().cpu(), vae.params['ORG_DICT']) if rank == 0 else []
     if rank == 0:
         save_path = args.save_path
         if save_path is None:

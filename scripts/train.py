@@ -28,7 +28,8 @@ def train(args):
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
         dist.init_process_group('nccl')
-    ops.set_compute_dtype(args.compute_dtype)
+    if args.compute_dtype is not None:             # otherwise TVAE_COMPUTE_DTYPE (read at import) or exact fp32
+        ops.set_compute_dtype(args.compute_dtype)
 
     # resuming: the KL annealer restarts from where the finished epochs left beta (reference :16-21)
     if args.checkpoint is not None:

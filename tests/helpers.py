@@ -112,3 +112,53 @@ def rel_l2(a, b):
     if nb < 1e-12:          # analytically-zero reference: fall back to an absolute bound
         return float(np.linalg.norm(a - b)) / 10.0
     return float(np.linalg.norm(a - b) / nb)
+
+
+PARITY_DIR = os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out", "parity")
+
+
+def record(name, lines):
+    """Append measured parity numbers to gpurun_out/parity/<name>.txt (the directory gpurun brings back from the GPU
+    box; the round's tables are copied from there into profiles/).  pytest -q drops what tests print: this keeps it."""
+    try:
+        os.makedirs(PARITY_DIR, exist_ok=True)
+        with open(os.path.join(PARITY_DIR, name + ".txt"), "a") as f:
+            for ln in ([lines] if isinstance(lines, str) else lines):
+                f.write(ln.rstrip("\n") + "\n")
+    except OSError:
+        pass
+
+
+# RELATIVE margins (oracle.gate_margins: distance from the switching point / the layer's rms pre-activation, float64)
+# below which a bottleneck gate of a molecule counts as "unsafe".  An fp32 implementation's error on such a pre-activation
+# is 3e-7 .. 1e-6 of that rms (K = 700 .. 2300 products), so 4e-6 leaves a factor of four; a deconv2 unit is one of
+# 32,512 output units per molecule and moves gradients 4x less (the weight tools/make_goldens.py gives it)
+GATE_THRESHOLDS = dict(pool0=4e-6, crelu0=4e-6, pool1=4e-6, crelu1=4e-6, pool2=4e-6, crelu2=4e-6,
+                       dlin=4e-6, deconv0=4e-6, deconv1=4e-6, deconv2=1e-6)
+# hidden ReLU of the seven feed-forward blocks (910,000 gates per trans4x-256 molecule): measured on the MI355X
+# (tools/debug/ffn_big.py) the fp32 GEMM decides 5 of 65 M such gates differently from float64, all with |pre| < 2e-7;
+# ONE such flip moves the gradients on the input side of that block by 1e-4
+FFN_GATE_THRESHOLD = 1e-6
+
+
+def gate_safe_rows(P64, toks, eps, thresholds=None, piece=96):
+    """(bool (n,) of molecules whose every bottleneck gate clears its threshold, {gate: unsafe molecules})"""
+    from oracle import tvae_oracle as O
+    th = thresholds or GATE_THRESHOLDS
+    parts = []
+    for lo in range(0, toks.shape[0], piece):
+        parts.append(O.gate_margins(P64, toks[lo:lo + piece], eps[lo:lo + piece].double()))
+    m = {k: torch.cat([p[k] for p in parts]) for k in parts[0]}
+    safe = torch.ones(toks.shape[0], dtype=torch.bool)
+    unsafe = {}
+    for k, t in th.items():
+        bad = m[k] < t
+        unsafe[k] = int(bad.sum())
+        safe &= ~bad
+    ffn_bad = torch.zeros_like(safe)
+    for k in m:
+        if k.startswith("ffn:"):
+            ffn_bad |= m[k] < FFN_GATE_THRESHOLD
+    unsafe["ffn (7 blocks)"] = int(ffn_bad.sum())
+    safe &= ~ffn_bad
+    return safe, unsafe

@@ -5,8 +5,9 @@ against the float64 oracle.
   * the one-pass batch of 500 with per-chunk loss normalisation == the reference's literal loop over 5
     chunks of 100 (transvae/trans_models.py:202-236): same per-chunk loss rows (2e-6), same accumulated
     gradients up to gate flips;
-  * one full chunk of 100 SMILES-shaped molecules: the five loss terms within 1e-5 of the oracle's float64
-    run, gradients at the level a few marginal ReLU / MaxPool gates allow (see _report_and_check);
+  * one full chunk of 100 SMILES-shaped molecules, chosen gate-safe from 448 candidates by the oracle's float64 gate
+    margins (the unsafe ones counted and reported): loss terms within 1e-5 and every gradient tensor at the bar of
+    the golden test;
   * greedy decode is row-wise: decoding a slab of latents at once, in pieces, or in another order gives
     the same token rows bit for bit (what sharding the latents over ranks relies on).
 """
@@ -63,50 +64,77 @@ def test_batch500_one_pass_equals_the_chunk_loop_4x256():
         else:
             errs[k] = rel_l2(grads[0][k], grads[1][k])
     _report_and_check("one pass vs chunk loop, batch 500", errs)
+    from helpers import record
+    from transvae_amd import ops
+    record("fullsize_batch500_fused_vs_loop_%s" % ops.compute_dtype(),
+           ["# one pass over 500 with per-chunk normalisation vs the literal loop over 5 chunks of 100 (both on the HIP path)",
+            "loss table max rel diff %.2e" % float(np.abs(tables[0] - tables[1]).max() / np.abs(tables[1]).max())] +
+           ["%-58s %10.2e" % (k, e) for k, e in sorted(errs.items(), key=lambda kv: -kv[1])])
 
 
-def test_full_chunk_of_100_against_the_float64_oracle_4x256():
+def test_full_chunk_of_100_gate_safe_molecules_at_the_golden_bar_4x256():
+    """A FULL chunk (100 SMILES-shaped molecules, trans4x-256) against the float64 oracle at the bar of the golden
+    test (tests/test_model_gpu.py: every loss term 1e-5; every gradient tensor within max(2e-5, 10 x the error of a
+    plain fp32 run of the same arithmetic on the same inputs); as many tensors within 1e-5 as that fp32 run manages).
+
+    What makes that bar meaningful at this size: ReLU / MaxPool gates.  Among ~8e6 bottleneck gates of a random chunk
+    a few dozen sit within fp32 rounding of their switching point and decide differently in ANY two fp32
+    implementations, which moves whole gradient tensors by 1e-4 .. 5e-3 and says nothing about the arithmetic.  So the
+    oracle's float64 gate margins (bottleneck gates and the hidden ReLUs of the feed-forward blocks) are computed for 448
+    candidate molecules, the molecules with a gate inside the
+    unsafe band (helpers.GATE_THRESHOLDS) are counted and set aside, and the chunk is the first 100 safe ones.  The
+    counts and the measured per-tensor table go to gpurun_out/parity/ (committed under profiles/ per round)."""
     from oracle import tvae_oracle as O
-    from transvae_amd import synth
+    from transvae_amd import ops, synth
+    from helpers import gate_safe_rows, record
     from test_model_gpu import run_chunk
-    toks = synth.synth_tokens(100, seed=101)
-    props = torch.zeros(100)
-    eps = torch.randn(100, 128, generator=torch.Generator().manual_seed(12))
+    n_cand, n_chunk = 448, 100
+    cand = synth.synth_tokens(n_cand, seed=101)
+    eps_c = torch.randn(n_cand, 128, generator=torch.Generator().manual_seed(12))
+    P = oracle_params("4x256_zinc", torch.float64, requires_grad=True)
+    safe, unsafe = gate_safe_rows(P, cand, eps_c)
+    idx = torch.nonzero(safe)[:, 0][:n_chunk]
+    tag = "fullsize_chunk100_%s" % ops.compute_dtype()
+    record(tag, ["# full chunk vs fp64 oracle, trans4x-256, mode %s" % ops.compute_dtype(),
+                 "candidates %d, molecules with every gate outside the unsafe band %d, used %d"
+                 % (n_cand, int(safe.sum()), len(idx)),
+                 "molecules set aside per gate type (relative margin below threshold): %s" % unsafe])
+    assert len(idx) == n_chunk, "only %d gate-safe molecules among %d candidates" % (len(idx), n_cand)
+    toks, eps, props = cand[idx], eps_c[idx], torch.zeros(n_chunk)
     vae = build("4x256_zinc")
     vae.model.eval()
     out, _ = run_chunk(vae, toks, props, eps, 0.02)
     out[0].backward()
     got = np.array([float(o) for o in out])
-    P = oracle_params("4x256_zinc", torch.float64, requires_grad=True)
     w = torch.tensor(synth.load_vocab(CONFIGS["4x256_zinc"]["vocab"])[2], dtype=torch.float64)
     losses, _ = O.chunk_loss(P, toks, props.double(), w, 0.02, eps=eps.double())
     losses[0].backward()
     want = np.array([float(x) for x in losses])
     np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-7)
-    named = dict(vae.model.named_parameters())
-    errs = {}
-    for k, p in named.items():
-        ref = P[k].grad.numpy()
-        if np.linalg.norm(ref) < 1e-10:
-            continue
-        errs[k] = rel_l2(p.grad.cpu(), ref)
-    _report_and_check("full chunk of 100 vs the fp64 oracle", errs)
-    # the same yardstick the golden test uses: how far does a plain fp32 run of the reference's own
-    # arithmetic (the oracle in float32 on the host) land from the float64 truth on THESE inputs?
+    # the yardstick: the same arithmetic in plain fp32 on the host (the oracle in float32) against the float64 truth
     P32 = oracle_params("4x256_zinc", torch.float32, requires_grad=True)
     l32, _ = O.chunk_loss(P32, toks, props, w.float(), 0.02, eps=eps)
     l32[0].backward()
-    ref = {k: rel_l2(P32[k].grad.double().numpy(), P[k].grad.numpy()) for k in errs}
-    rv, mv = np.array(list(ref.values())), np.array(list(errs.values()))
-    print("    the oracle's own fp32 run vs fp64 on the same chunk: median %.2e, 80%% %.2e, worst %.2e"
-          % (float(np.median(rv)), float(np.sort(rv)[int(0.8 * len(rv))]), float(rv.max())))
-    for k, e in sorted(errs.items(), key=lambda kv: -kv[1])[:16]:
-        print("    %-55s mine %.2e   oracle fp32 %.2e" % (k, e, ref[k]))
-    # Which gates flip differs between any two fp32 implementations, and ONE flipped gate behind
-    # decoder.linear (576 ReLUs per molecule, 100 molecules) moves that weight's gradient by ~4e-3 and
-    # z_var's with it -- seen here -- so only the bulk is compared with the fp32 yardstick; the cap on the
-    # worst tensor is _report_and_check's.
-    assert float(np.median(mv)) < max(2e-5, 5.0 * float(np.median(rv)))
+    named = dict(vae.model.named_parameters())
+    errs, ref = {}, {}
+    for k, p in named.items():
+        truth = P[k].grad.numpy()
+        if np.linalg.norm(truth) < 1e-10:              # key-projection biases: analytically zero
+            assert float(p.grad.abs().max()) < 1e-5, k
+            continue
+        errs[k] = rel_l2(p.grad.cpu(), truth)
+        ref[k] = rel_l2(P32[k].grad.double().numpy(), truth)
+    mv, rv = np.array(list(errs.values())), np.array(list(ref.values()))
+    n_tight, ref_tight = int((mv < 1e-5).sum()), int((rv < 1e-5).sum())
+    record(tag, ["losses rel err vs fp64: %s" % np.array2string(np.abs(got - want) / np.maximum(np.abs(want), 1e-12), precision=1),
+                 "gradient rel-L2 vs fp64: mine median %.2e worst %.2e, %d/%d within 1e-5 | host fp32 run median %.2e worst %.2e, %d/%d within 1e-5"
+                 % (np.median(mv), mv.max(), n_tight, len(mv), np.median(rv), rv.max(), ref_tight, len(rv)),
+                 "%-58s %10s %10s %10s" % ("tensor", "mine", "host fp32", "bar")] +
+           ["%-58s %10.2e %10.2e %10.2e" % (k, errs[k], ref[k], max(2e-5, 10 * ref[k])) for k in sorted(errs, key=errs.get, reverse=True)])
+    for k, e in errs.items():
+        assert e < max(2e-5, 10.0 * ref[k]), (k, e, ref[k])
+    assert n_tight >= 0.8 * ref_tight, (n_tight, ref_tight)
+    assert float(np.median(mv)) < max(5e-6, 2.0 * float(np.median(rv)))
 
 
 def test_decode_is_row_wise_at_slab_size_4x256():

@@ -96,3 +96,63 @@ def test_shell_defaults_and_state_dict_keys(tmp_path):
     vae.save(vae.current_state, "best", path=str(tmp_path))
     vae.save(vae.current_state, "007.ckpt", path=str(tmp_path))
     assert sorted(os.listdir(tmp_path)) == ["007_x.ckpt", "best_x.ckpt"]
+
+
+REF_CKPT = os.path.join(ROOT, "tests", "golden", "ref_tiny.ckpt")
+
+
+def test_checkpoint_written_by_the_reference_loads_with_the_safe_loader():
+    """tests/golden/ref_tiny.ckpt was written by the REFERENCE's own VAEShell.save after one NoamOpt.step
+    (tools/make_goldens.py golden_ckpt; reference trans_models.py:69-92).  TransVAE(load_fn=...) must read it with the
+    safe unpickler (np.float64 best_loss and all), rebuild the architecture from the stored params, restore every
+    tensor bit for bit and carry the Noam step on (reference load, :94-124, opt.py:38-39).  The greedy tokens that
+    state decodes to are checked on the GPU (tests/test_model_gpu.py)."""
+    from transvae_amd.trans_models import TransVAE
+    g = load("ref_ckpt")
+    assert os.environ.get("TVAE_TRUSTED_CKPT") != "1"            # the SAFE loader is what is being tested
+    vae = TransVAE(load_fn=REF_CKPT)
+    assert vae.name == "tiny" and vae.n_epochs == int(g["epoch"]) and float(vae.best_loss) == float(g["best_loss"])
+    assert [vae.params[k] for k in ("N", "d_model", "d_ff", "d_latent", "h")] == [1, 64, 64, 32, 2]
+    assert vae.params["WARMUP_STEPS"] == 10000          # not an arch param: the constructor's default wins (reference :115-119)
+    sd = vae.model.state_dict()
+    assert list(sd) == [str(k) for k in g["keys"]]
+    np.testing.assert_allclose([float(v.double().sum()) for v in sd.values()], g["sums"], rtol=0, atol=0)
+    st = vae.optimizer.state_dict
+    assert st["step"] == int(g["noam_step"]) == 1 and st["rate"] == float(g["noam_rate"])
+    assert len(st["state"]) == int(g["opt_state_entries"])
+    # the next step continues the schedule from the stored step
+    assert abs(vae.optimizer.rate(st["step"] + 1) - 64 ** -0.5 * 2 * 10000 ** -1.5) < 1e-18
+
+
+def test_checkpoint_written_by_the_build_was_loaded_by_the_reference():
+    """The other direction, recorded in the container by tools/make_goldens.py (the reference cannot run on the GPU
+    box): a checkpoint written by this package's VAEShell.save went through the reference's VAEShell.load; it saw
+    the same state_dict keys in the same order and every tensor bit for bit."""
+    from transvae_amd import synth
+    from transvae_amd.trans_models import TransVAE
+    g = load("ref_ckpt")
+    assert bool(g["reverse_loaded"]) and bool(g["reverse_keys_equal"]) and bool(g["reverse_tensors_equal"])
+    assert int(g["reverse_epoch"]) == 7 and g["reverse_arch"].tolist() == [1, 64, 64, 32, 2]
+    cd, od, w = synth.load_vocab("zinc")
+    mine = TransVAE(params={"CHAR_DICT": cd, "ORG_DICT": od, "CHAR_WEIGHTS": w}, name="mine", N=1, d_model=64, d_ff=64,
+                    d_latent=32, h=2)
+    assert [str(k) for k in g["reverse_keys"]] == list(mine.model.state_dict())
+
+
+def test_sample_from_memory_matches_the_reference_draw_for_draw():
+    """VAEShell.sample_from_memory is host code over torch's and numpy's global generators (reference
+    trans_models.py:355-381): under the same seeds the three modes must give the reference's z bit for bit."""
+    from transvae_amd import synth
+    from transvae_amd.trans_models import TransVAE
+    g = load("sampling")
+    cd, od, w = synth.load_vocab("zinc")
+    vae = TransVAE(params={"CHAR_DICT": cd, "ORG_DICT": od, "CHAR_WEIGHTS": w}, name="s", **synth.ARCHS["trans1x-128"])
+    torch.manual_seed(int(g["torch_seed"]))
+    np.random.seed(int(g["numpy_seed"]))
+    dims, pool = g["dims"].tolist(), g["pool"].tolist()
+    assert np.array_equal(vae.sample_from_memory(7, mode="rand").numpy(), g["rand"])
+    assert np.array_equal(vae.sample_from_memory(7, mode="top_dims", sample_dims=dims).numpy(), g["top_dims"])
+    assert np.array_equal(vae.sample_from_memory(7, mode="k_dims", sample_dims=pool, k=3).numpy(), g["k_dims"])
+    assert np.array_equal(vae.sample_from_memory(5, mode="k_dims", sample_dims=pool, k=5).numpy(), g["k_dims_again"])
+    with pytest.raises(AssertionError):
+        vae.sample_from_memory(3, mode="top_dims")

@@ -74,7 +74,7 @@ def test_train_chunk_matches_reference_golden_and_oracle(cfg_name, gemm_mode):
     # backward.  Bar: per-tensor relative L2 vs the fp64 truth
     #   * at least 0.8x as many tensors within 1e-5 (north star) as the reference's own fp32 run
     #     manages on these inputs, median below max(5e-6, 2x the reference's median);
-    #   * every tensor within max(4e-5, 10x the reference's OWN fp32 rounding error on that tensor
+    #   * every tensor within max(2e-5 [4e-5 in 3xbf16 mode], 10x the reference's OWN fp32 rounding error on that tensor
     #     (its fp32 run vs its fp64 run, stored in the golden)).  The tensors above 1e-5 are the
     #     source-attention query/key projections and the LayerNorm in front of them: with the
     #     near-uniform attention of these weights dS = P (dP - sum P dP) cancels 2-3 digits in ANY
@@ -89,7 +89,11 @@ def test_train_chunk_matches_reference_golden_and_oracle(cfg_name, gemm_mode):
     keys = [str(k) for k in g["grad_keys"]]
     assert set(keys) == set(named)
     ref_err = {k: float(e) for k, e in zip(keys, g["grad_ref_f32_relerr"])}
-    tol = {k: max(4e-5, 10.0 * ref_err[k]) for k in keys}
+    # floor: measured worst over the three configs where the reference's own error is below 4e-6: 1.05e-5 in exact fp32
+    # (profiles/r2_parity_golden_step_fp32.txt) -> 2e-5; the 3xbf16 arithmetic has one marginal gate of
+    # 4x256_pubchem_pp deciding differently (3.2e-5 on two tensors, profiles/r2_parity_golden_step_f32x3.txt) -> 4e-5
+    floor = 2e-5 if gemm_mode == "fp32" else 4e-5
+    tol = {k: max(floor, 10.0 * ref_err[k]) for k in keys}
     # (1) reference summaries: gradient norm of every tensor
     for i, k in enumerate(keys):
         gr = named[k].grad.detach().cpu().double().numpy().ravel()
@@ -120,6 +124,17 @@ def test_train_chunk_matches_reference_golden_and_oracle(cfg_name, gemm_mode):
                                          ref_err[worst], n_tight, len(errs)))
     for k, e in sorted(errs.items(), key=lambda kv: -kv[1])[:14]:
         print("    %-55s mine %.2e   reference fp32 %.2e" % (k, e, ref_err[k]))
+    from helpers import record
+    ref_vals_all = np.array([ref_err[k] for k in errs])
+    record("golden_step_%s" % gemm_mode,
+           ["# %s, mode %s: loss terms rel err vs reference fp64 %s" % (cfg_name, gemm_mode, np.array2string(
+               np.abs(got - g["loss_f64"]) / np.maximum(np.abs(g["loss_f64"]), 1e-12), precision=1)),
+            "gradient rel-L2 vs fp64: mine median %.2e worst %.2e, %d/%d within 1e-5 | reference's own fp32 run median %.2e worst "
+            "%.2e, %d/%d within 1e-5" % (float(np.median(list(errs.values()))), errs[worst], n_tight, len(errs),
+                                         float(np.median(ref_vals_all)), float(ref_vals_all.max()),
+                                         int((ref_vals_all < 1e-5).sum()), len(errs)),
+            "%-58s %10s %10s %10s" % ("tensor", "mine", "ref fp32", "bar")] +
+           ["%-58s %10.2e %10.2e %10.2e" % (k, e, ref_err[k], tol[k]) for k, e in sorted(errs.items(), key=lambda kv: -kv[1])])
     for k, e in errs.items():
         assert e < tol[k], (k, e, tol[k])
     # aggregate bars, relative to how well the reference's own fp32 run does on the same inputs
@@ -174,6 +189,13 @@ def test_train_chunk_bf16_mode_within_1e_2(cfg_name, gemm_mode):
           % (cfg_name, np.array2string(np.abs(got - g["loss_f64"]) / np.maximum(np.abs(g["loss_f64"]), 1e-12), precision=1),
              float(np.median(list(nerr.values()))), nerr[worst_n], worst_n,
              float(np.median(list(ferr.values()))), ferr[worst_f], worst_f))
+    from helpers import record
+    record("golden_step_bf16", ["# %s, mode bf16: loss terms rel err vs reference fp64 %s" % (cfg_name, np.array2string(
+        np.abs(got - g["loss_f64"]) / np.maximum(np.abs(g["loss_f64"]), 1e-12), precision=1)),
+        "gradient-norm error median %.2e worst %.2e (%s); full-gradient rel-L2 (the %d tensors the golden holds in full) median %.2e worst %.2e (%s)"
+        % (float(np.median(list(nerr.values()))), nerr[worst_n], worst_n, len(ferr), float(np.median(list(ferr.values()))), ferr[worst_f], worst_f),
+        "%-58s %10s %10s" % ("tensor", "norm err", "full rel-L2")] +
+        ["%-58s %10.2e %10s" % (k, e, ("%.2e" % ferr[k]) if k in ferr else "-") for k, e in sorted(nerr.items(), key=lambda kv: -kv[1])])
     assert float(np.median(list(nerr.values()))) < 1e-2
     assert nerr[worst_n] < 5e-2
     assert float(np.median(list(ferr.values()))) < 3e-2
@@ -240,8 +262,8 @@ def test_graph_replayed_decode_is_the_same_decode(gemm_mode):
     want = g["ids"].astype(np.int64)
     for call in range(3):                                     # eager, capture + replay, replay
         assert np.array_equal(vae.greedy_decode(z).cpu().numpy(), want), call
-    graphs = vae.model._tvae_decode_graphs
-    assert sum(1 for k in graphs if k[0] != "seen") == 1
+    graphs = vae.model._tvae_decode_graphs["graphs"]
+    assert len(graphs) == 1
     z2 = torch.flip(z, [0])                                   # other latents through the captured graph
     assert np.array_equal(vae.greedy_decode(z2).cpu().numpy(), want[::-1])
     lens_e = torch.from_numpy(np.resize(g["mask_lens_explicit"], 32).astype(np.int64))
@@ -261,6 +283,14 @@ def test_graph_replayed_decode_is_the_same_decode(gemm_mode):
     assert not np.array_equal(moved, want)
     for call in range(3):
         assert np.array_equal(vae.greedy_decode(z).cpu().numpy(), moved), call
+    # the cache is bounded: new batch sizes push the least recently used graph out, results stay the reference's
+    for nb in (5, 6, 7, 9, 10, 11):
+        for call in range(2):
+            vae.greedy_decode(z[:nb])
+    assert len(graphs) <= decode.GRAPH_CACHE_MAX
+    assert np.array_equal(vae.greedy_decode(z).cpu().numpy(), moved)
+    decode.clear_decode_graphs(vae.model)
+    assert "_tvae_decode_graphs" not in vae.model.__dict__
 
 
 def test_reference_style_decode_loop_matches_cached_decoder():
@@ -282,10 +312,12 @@ def test_reference_style_decode_loop_matches_cached_decoder():
     assert np.array_equal(decoded[:, 1:].cpu().numpy(), g["ids"][:4, :12].astype(np.int64))
 
 
-def test_attention_weight_dump_matches_reference():
+@pytest.mark.parametrize("cfg_name", ["1x128_zinc", "4x256_pubchem_pp"])
+def test_attention_weight_dump_matches_reference(cfg_name):
+    "forward_w_attn (scripts/attention.py path): dk = 32, and dk = 64 on BASELINE config 5's model (PubChem vocab + property head)"
     from transvae_amd.data import make_src_mask, make_std_mask
-    g = load("attn_1x128_zinc")
-    vae = build("1x128_zinc")
+    g = load("attn_" + cfg_name)
+    vae = build(cfg_name)
     vae.model.eval()
     src = torch.from_numpy(g["tokens"].astype(np.int64)).cuda()
     tgt = src[:, :-1]
@@ -369,3 +401,62 @@ def test_fused_chunks_equal_literal_chunk_loop():
             assert np.linalg.norm(grads[0][k]) < 1e-5 and np.linalg.norm(grads[1][k]) < 1e-5
         else:
             assert rel_l2(grads[0][k], grads[1][k]) < 2e-5, k
+
+
+def test_reference_written_checkpoint_decodes_to_the_reference_tokens():
+    """tests/golden/ref_tiny.ckpt (written by the reference's VAEShell.save, read here by the safe loader) must put the
+    model in the state the reference decoded from: mask lengths and greedy tokens bit for bit (ref_ckpt.npz)."""
+    from transvae_amd.trans_models import TransVAE
+    g = load("ref_ckpt")
+    vae = TransVAE(load_fn=os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_tiny.ckpt"))
+    z = torch.from_numpy(g["z"])
+    lens = vae.model.encoder.predict_mask_length(z.cuda())
+    assert np.array_equal(lens.cpu().numpy()[:, 0], g["mask_len"].astype(np.int64))
+    assert np.array_equal(vae.greedy_decode(z).cpu().numpy(), g["ids"].astype(np.int64))
+
+
+def test_adamopt_over_the_fused_kernel_matches_the_reference():
+    """AdamOpt(params, 3e-4, Adam) -- the reference's fixed-rate wrapper (opt.py:41-52) -- over the one-launch Adam:
+    three steps against what the reference's AdamOpt over torch.optim.Adam did with the same gradients (sampling.npz)."""
+    from transvae_amd.opt import Adam, AdamOpt
+    g = load("sampling")
+    n = int(g["adamopt_n"])
+    ps = [torch.nn.Parameter(torch.from_numpy(g["adamopt_p0/%d" % i]).cuda()) for i in range(n)]
+    opt = AdamOpt(ps, float(g["adamopt_lr"]), Adam)
+    assert opt.optimizer.param_groups[0]["lr"] == 3e-4 and opt.optimizer.param_groups[0]["betas"] == (0.9, 0.999)
+    for step in range(1, 4):
+        for i, p in enumerate(ps):
+            p.grad = torch.from_numpy(g["adamopt_g%d/%d" % (step, i)]).cuda()
+        opt.step()
+        for i, p in enumerate(ps):
+            want, p0 = g["adamopt_p%d/%d" % (step, i)], g["adamopt_p0/%d" % i]
+            assert rel_l2(p.detach().cpu().numpy() - p0, want - p0) < 2e-6, (step, i)
+    assert opt.state_dict["state"][0]["step"] == 3 and opt.state_dict["param_groups"][0]["lr"] == 3e-4
+
+
+def test_steps_queued_without_a_sync_equal_steps_synced_one_by_one():
+    """The host queues train steps ahead of the GPU (train() reads losses two steps late, bench.py never syncs):
+    every step must still get ITS learning rate and bias corrections.  Eight steps back to back with no
+    synchronisation against the same eight steps with a device sync after each: identical weights."""
+    from transvae_amd import synth
+    toks = synth.synth_tokens(24, seed=5).float()
+    data = torch.cat([toks, torch.zeros(24, 1)], 1).cuda()
+    eps = torch.randn(24, 128, generator=torch.Generator().manual_seed(4)).cuda()
+    finals = []
+    for sync in (False, True):
+        vae = build("1x128_zinc", BATCH_SIZE=24, BATCH_CHUNKS=2, WARMUP_STEPS=400)    # linear ramp: the rate of step t is t x the rate of step 1
+        vae.model.eval()
+        torch.cuda.synchronize()
+        for _ in range(8):
+            vae.train_step(data, 0.02, eps=eps)
+            if sync:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        finals.append({k: p.detach().cpu().numpy().copy() for k, p in vae.model.named_parameters()})
+    for k in finals[0]:
+        # split-K atomics add in arrival order, so two runs of the same steps differ in the last bits; a step taken with a
+        # neighbouring step's rate would move a weight by 12-100 % of its update
+        if k.endswith("attn.linears.1.bias"):      # analytically zero gradient: Adam normalises pure rounding noise
+            continue
+        p0 = synth.synth_tensor(k, finals[1][k].shape, 0)
+        assert rel_l2(finals[0][k] - p0, finals[1][k] - p0) < 0.02, k

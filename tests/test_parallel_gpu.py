@@ -19,6 +19,12 @@ ARCH = "trans1x-128"
 PER_RANK, CHUNKS = 8, 2
 
 
+def _set_case(arch, per_rank, chunks):
+    "module-level so that spawned workers (which re-import this file) can be told the case through their arguments"
+    global ARCH, PER_RANK, CHUNKS
+    ARCH, PER_RANK, CHUNKS = arch, per_rank, chunks
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -52,7 +58,8 @@ def _moments(vae):
     return {k: opt.state[p]["exp_avg"].detach().cpu().numpy().copy() for k, p in vae.model.named_parameters()}
 
 
-def _worker(rank, world, port, reduce, overlap, q):
+def _worker(rank, world, port, reduce, overlap, q, case=("trans1x-128", 8, 2)):
+    _set_case(*case)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -71,16 +78,20 @@ def _worker(rank, world, port, reduce, overlap, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("reduce,overlap", [("sum", True), ("mean", True), ("sum", False)])
-def test_two_ranks_equal_one_process_on_the_global_batch(reduce, overlap):
+@pytest.mark.parametrize("reduce,overlap,case", [("sum", True, ("trans1x-128", 8, 2)), ("mean", True, ("trans1x-128", 8, 2)),
+                                                 ("sum", False, ("trans1x-128", 8, 2)),
+                                                 # BASELINE config 3's model at the reference's chunk size: trans4x-256, 100 per rank
+                                                 ("mean", True, ("trans4x-256", 100, 1))])
+def test_two_ranks_equal_one_process_on_the_global_batch(reduce, overlap, case):
     world = 2
+    _set_case(*case)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, reduce, overlap, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, reduce, overlap, q, case)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=100) for _ in range(world)], key=lambda t: t[0])
+    res = sorted([q.get(timeout=200) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -110,6 +121,7 @@ def test_two_ranks_equal_one_process_on_the_global_batch(reduce, overlap):
 
 
 def _train_worker(rank, world, port, tmp, q):
+    _set_case("trans1x-128", 8, 2)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     os.chdir(tmp)
     torch.cuda.set_device(0)
@@ -121,12 +133,16 @@ def _train_worker(rank, world, port, tmp, q):
     torch.manual_seed(100 + rank)                       # the reparameterisation noise differs per rank, as in a real run
     vae.train(mols, mols[:40], epochs=2, save=True, save_freq=2, log=True, log_dir="trials")
     sd = {k: v.detach().cpu().numpy().copy() for k, v in vae.model.state_dict().items()}
+    # train() closed its data-parallel engine: no hooks left behind, the optimizer's gradient scale back to 1
+    assert vae._dp.closed and vae.optimizer.optimizer.grad_scale == 1.0
+    assert all(len(p._post_accumulate_grad_hooks or {}) == 0 for p in vae.model.parameters())
     q.put((rank, sd, vae.n_epochs, float(vae.best_loss)))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_two_rank_train_loop(tmp_path):
+    _set_case("trans1x-128", 8, 2)
     """VAEShell.train under torch.distributed: every rank walks its DistributedSampler share of the HBM-resident
     dataset, gradients are all-reduced, only rank 0 logs and saves, and the ranks end with identical weights and
     the same best-loss decision."""

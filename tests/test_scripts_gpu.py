@@ -106,3 +106,32 @@ def test_bench_data_parallel_path_over_rccl_with_one_rank():
                      env={"TVAE_BENCH_FORCE_DP": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29577"})
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["decode_mols_per_s"] > 0
     assert out["final_loss"] == out["final_loss"] and 0 < out["final_loss"] < 100        # finite, sane
+
+
+def test_bench_gpus_2_launches_its_own_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's N = 1 command, with N = 2): the
+    script starts two ranks itself and reports n_gpus == 2.  On a one-GPU box the two ranks share cuda:0 over gloo
+    (TVAE_BENCH_REHEARSE=1; numbers meaningless) -- trans4x-256, 100 molecules per rank, the data-parallel step, the
+    sharded decode and the gather of token ids all run."""
+    out = _run_bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "100", "--chunks", "1", "--decode-n", "128",
+                     "--no-extra-modes", "--no-cpu-baseline", env={"TVAE_BENCH_REHEARSE": "1"})
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 200 and out["config"]["parallelism"] == "dp2"
+    dp = out["data_parallel"]
+    assert len(dp["ms_per_step_per_rank"]) == 2 and len(dp["allreduce_wait_ms_per_step_per_rank"]) == 2
+    assert dp["gradient_bytes_per_step"] >= 4 * 7876205 and dp["buckets"] >= 2
+    assert abs(out["value"] - 2 * 100 * 126 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+    assert 0 < out["final_loss"] < 100 and out["decode_mols_per_s"] > 0
+
+
+def test_bench_refuses_a_world_size_it_cannot_run():
+    "without the rehearsal switch --gpus 2 on a one-GPU box is an error, never a line that says n_gpus 1 or 2"
+    import subprocess
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has two GPUs")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True,
+                       text=True, timeout=120, env={k: v for k, v in os.environ.items() if k not in ("TVAE_BENCH_REHEARSE", "WORLD_SIZE")})
+    assert r.returncode != 0 and r.stdout.strip() == "" and "refusing" in r.stderr
+    # a launcher that disagrees with the flag is refused too
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True,
+                       text=True, timeout=120, env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and r.stdout.strip() == "" and "disagree" in r.stderr

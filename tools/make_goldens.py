@@ -331,8 +331,9 @@ def golden_decode(tm, name, cfg, n=32):
           "distinct tokens", len(np.unique(ids.numpy())))
 
 
-def golden_attn(tm, data_mod):
-    name, cfg = "1x128_zinc", CONFIGS["1x128_zinc"]
+def golden_attn(tm, data_mod, name="1x128_zinc"):
+    "forward_w_attn dumps; 1x128_zinc pins dk = 32, 4x256_pubchem_pp is BASELINE config 5's model (dk = 64, property head)"
+    cfg = CONFIGS[name]
     vae = build(tm, cfg)
     from transvae_amd import synth
     toks = synth.synth_tokens(2, seed=5, lengths=[30, 126])
@@ -350,13 +351,117 @@ def golden_attn(tm, data_mod):
     finally:
         torch.randn_like = orig
     heads = [0, 3]
-    np.savez_compressed(os.path.join(OUT, "attn_1x128_zinc.npz"), tokens=toks.numpy().astype(np.int8),
+    np.savez_compressed(os.path.join(OUT, "attn_%s.npz" % name), tokens=toks.numpy().astype(np.int8),
                         eps=eps.numpy(), heads=np.array(heads),
                         enc=np.stack([w[:, heads].numpy() for w in enc_w]).astype(np.float16),
                         fin=fin_w[0][:, heads].numpy().astype(np.float16),
                         src=np.stack([w[:, heads].numpy() for w in src_w]).astype(np.float16),
                         x_rows=x[:, :4].numpy())
-    print("attn", [tuple(w.shape) for w in enc_w], tuple(fin_w[0].shape), [tuple(w.shape) for w in src_w])
+    print("attn", name, [tuple(w.shape) for w in enc_w], tuple(fin_w[0].shape), [tuple(w.shape) for w in src_w])
+
+
+TINY = dict(N=1, d_model=64, d_ff=64, d_latent=32, h=2)      # smallest architecture the reference's conv stack allows
+
+
+def golden_ckpt(tm, loss_mod, data_mod):
+    """Checkpoint interop, both directions (reference trans_models.py:69-124, opt.py:17-19, 38-39).
+
+    (1) The REFERENCE builds a tiny model (N=1, d_model 64, 2 heads: the .ckpt is 7 MB, most of it the two (1,5000,64)
+        positional buffers the format carries), takes one accumulate + NoamOpt.step, fills current_state the way its
+        train() does (np.float64 best_loss included -- the value that makes torch >= 2.6 refuse the file by default) and
+        writes tests/golden/ref_tiny.ckpt with ITS OWN VAEShell.save.  ref_ckpt.npz holds what the reference decodes from
+        that state, its Noam step/rate and checksums of every tensor.
+    (2) The BUILD (transvae_amd, CPU side: no kernel runs) writes a checkpoint with its VAEShell.save; the reference's
+        VAEShell.load reads it (torch.load patched to weights_only=False: the file was written two lines above).  Recorded:
+        that it loaded, the state_dict keys it saw, and that every tensor arrived bit for bit."""
+    import tempfile
+    from transvae_amd import synth
+    from transvae_amd.trans_models import TransVAE as MyTransVAE
+    cd, od, w = synth.load_vocab("zinc")
+    vae = tm.TransVAE(params={"CHAR_DICT": cd, "ORG_DICT": od, "CHAR_WEIGHTS": w, "WARMUP_STEPS": 100}, name="tiny", **TINY)
+    vae.model.load_state_dict(synth.synth_state_dict(vae.model.state_dict(), 3))
+    vae.use_gpu = False
+    toks = synth.synth_tokens(6, seed=77, lengths=[3, 9, 14, 20, 25, 28])    # length classes < d_latent = 32
+    eps = torch.from_numpy(np.random.default_rng(5).standard_normal((6, TINY["d_latent"])).astype(np.float32))
+    run_chunk(tm, loss_mod, data_mod, vae, toks, torch.zeros(6), eps, 0.01, torch.float32)
+    vae.optimizer.step()
+    vae.n_epochs = 1
+    vae.best_loss = np.float64(3.25)
+    vae.current_state.update(epoch=vae.n_epochs, model_state_dict=vae.model.state_dict(),
+                             optimizer_state_dict=vae.optimizer.state_dict, best_loss=vae.best_loss)
+    vae.save(vae.current_state, "ref", path=OUT)                      # -> tests/golden/ref_tiny.ckpt
+    z = torch.from_numpy(np.random.default_rng(8).standard_normal((8, TINY["d_latent"])).astype(np.float32))
+    with torch.no_grad():
+        ids = vae.greedy_decode(z)
+        mask_len = vae.model.encoder.predict_mask_length(z).squeeze(-1)
+    sd = vae.model.state_dict()
+    rec = dict(z=z.numpy(), ids=ids.numpy().astype(np.int8), mask_len=mask_len.numpy().astype(np.int16),
+               noam_step=np.int64(vae.optimizer.state_dict["step"]), noam_rate=np.float64(vae.optimizer.state_dict["rate"]),
+               keys=np.array(list(sd)), sums=np.array([float(v.double().sum()) for v in sd.values()]),
+               best_loss=np.float64(vae.best_loss), epoch=np.int64(1),
+               opt_state_entries=np.int64(len(vae.optimizer.state_dict["state"])))
+    # ---- the other way round
+    mine = MyTransVAE(params={"CHAR_DICT": cd, "ORG_DICT": od, "CHAR_WEIGHTS": w}, name="mine", **TINY)
+    mine.model.load_state_dict(synth.synth_state_dict(mine.model.state_dict(), 4))
+    mine.n_epochs = 7
+    mine.optimizer.sync_state_dict()
+    mine.current_state.update(epoch=7, model_state_dict=mine.model.state_dict(),
+                              optimizer_state_dict=mine.optimizer.state_dict, best_loss=1.5)
+    with tempfile.TemporaryDirectory() as tmp:
+        mine.save(mine.current_state, "build", path=tmp)
+        path = os.path.join(tmp, "build_mine.ckpt")
+        orig = torch.load
+        torch.load = lambda *a, **k: orig(*a, **dict(k, weights_only=False))
+        try:
+            back = tm.TransVAE(load_fn=path)
+        finally:
+            torch.load = orig
+    bsd, msd = back.model.state_dict(), mine.model.state_dict()
+    rec["reverse_loaded"] = np.bool_(True)
+    rec["reverse_keys"] = np.array(list(bsd))
+    rec["reverse_keys_equal"] = np.bool_(list(bsd) == list(msd))
+    rec["reverse_tensors_equal"] = np.bool_(all(torch.equal(bsd[k], msd[k].cpu()) for k in msd))
+    rec["reverse_epoch"] = np.int64(back.n_epochs)
+    rec["reverse_arch"] = np.array([back.params[k] for k in ("N", "d_model", "d_ff", "d_latent", "h")])
+    np.savez_compressed(os.path.join(OUT, "ref_ckpt.npz"), **rec)
+    print("ckpt", os.path.getsize(os.path.join(OUT, "ref_tiny.ckpt")), "bytes; reverse:", bool(rec["reverse_keys_equal"]),
+          bool(rec["reverse_tensors_equal"]), "mask_len", mask_len.tolist())
+
+
+def golden_sampling(tm, opt_mod):
+    """Seeded host-side draws of VAEShell.sample_from_memory (trans_models.py:355-381) in its three modes, and three
+    steps of AdamOpt (opt.py:41-52) over torch.optim.Adam on small tensors with given gradients."""
+    vae = build(tm, CONFIGS["1x128_zinc"])
+    rec = {}
+    dims = [3, 17, 90]
+    pool = [1, 5, 9, 33, 64, 100, 127]
+    torch.manual_seed(123)
+    np.random.seed(5)
+    rec["rand"] = vae.sample_from_memory(7, mode="rand").numpy()
+    rec["top_dims"] = vae.sample_from_memory(7, mode="top_dims", sample_dims=dims).numpy()
+    rec["k_dims"] = vae.sample_from_memory(7, mode="k_dims", sample_dims=pool, k=3).numpy()
+    rec["k_dims_again"] = vae.sample_from_memory(5, mode="k_dims", sample_dims=pool, k=5).numpy()
+    rec.update(dims=np.array(dims), pool=np.array(pool), torch_seed=np.int64(123), numpy_seed=np.int64(5))
+    # AdamOpt: lr 3e-4, torch defaults (betas 0.9/0.999, eps 1e-8)
+    rng = np.random.default_rng(31)
+    shapes = [(25,), (40, 17), (4100,), (1,)]
+    ps = [torch.nn.Parameter(torch.from_numpy(rng.standard_normal(sh).astype(np.float32))) for sh in shapes]
+    for i, p0 in enumerate(ps):
+        rec["adamopt_p0/%d" % i] = p0.detach().numpy().copy()
+    ao = opt_mod.AdamOpt(ps, 3e-4, torch.optim.Adam)
+    for step in range(1, 4):
+        for i, pr in enumerate(ps):
+            g = torch.from_numpy(rng.standard_normal(shapes[i]).astype(np.float32))
+            rec["adamopt_g%d/%d" % (step, i)] = g.numpy()
+            pr.grad = g
+        ao.step()
+        for i, pr in enumerate(ps):
+            rec["adamopt_p%d/%d" % (step, i)] = pr.detach().numpy().copy()
+    rec["adamopt_lr"] = np.float64(3e-4)
+    rec["adamopt_n"] = np.int64(len(shapes))
+    np.savez_compressed(os.path.join(OUT, "sampling.npz"), **rec)
+    print("sampling", rec["rand"][0, :3], np.nonzero(rec["k_dims"][0])[0], np.nonzero(rec["k_dims_again"][0])[0])
+
 
 
 def golden_units(tm, loss_mod, util, opt_mod):
@@ -488,6 +593,13 @@ def main():
         return golden_data(data_mod, util)
     if len(sys.argv) > 1 and sys.argv[1] == "accum":
         return golden_accum(tm, loss_mod, data_mod)
+    if len(sys.argv) > 1 and sys.argv[1] == "ckpt":
+        return golden_ckpt(tm, loss_mod, data_mod)
+    if len(sys.argv) > 1 and sys.argv[1] == "sampling":
+        return golden_sampling(tm, opt_mod)
+    if len(sys.argv) > 1 and sys.argv[1] == "attn":
+        golden_attn(tm, data_mod)
+        return golden_attn(tm, data_mod, "4x256_pubchem_pp")
     if len(sys.argv) > 1 and sys.argv[1] == "step":
         for name, cfg in CONFIGS.items():
             golden_step(tm, loss_mod, data_mod, name, cfg)
@@ -498,6 +610,9 @@ def main():
     golden_decode(tm, "1x128_zinc", CONFIGS["1x128_zinc"])
     golden_decode(tm, "4x256_zinc", CONFIGS["4x256_zinc"])
     golden_attn(tm, data_mod)
+    golden_attn(tm, data_mod, "4x256_pubchem_pp")
+    golden_ckpt(tm, loss_mod, data_mod)
+    golden_sampling(tm, opt_mod)
     golden_units(tm, loss_mod, util, opt_mod)
     golden_data(data_mod, util)
 

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(LossArgs a0) {
         for (int t = lane; t < a.L + 1; t += 64) cnt += (a.tokens[(size_t)b * (a.L + 1) + t] != a.pad_idx);
         cnt = (int)wave_sum((float)cnt);
       }
-      int cls = cnt < a.n_len ? cnt : a.n_len - 1;
+      int cls = cnt < 0 ? 0 : (cnt < a.n_len ? cnt : a.n_len - 1);   // same clamp as loss_reduce_kernel
       const float* pl = a.pred_len + (size_t)b * a.n_len;
       float mx = -INFINITY;
       for (int c = lane; c < a.n_len; c += 64) mx = fmaxf(mx, pl[c]);
@@ -183,6 +183,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(LossArgs a0) {
 // ------------------------------------------------------------------------------- Adam
 __global__ __launch_bounds__(256) void adam_kernel(void* const* ptrs, const int64_t* sizes, const int32_t* chunk_tensor,
                                                    const int64_t* chunk_start, int n_tensors, const float* hyper,
+                                                   float lr_v, float bc1_v, float bc2_v, float gs_v,
                                                    float beta2, float omb1, float omb2, float eps, int zero_grad) {
   const int ti = chunk_tensor[blockIdx.x];
   const int64_t start = chunk_start[blockIdx.x];
@@ -191,7 +192,8 @@ __global__ __launch_bounds__(256) void adam_kernel(void* const* ptrs, const int6
   float* g = (float*)ptrs[n_tensors + ti];
   float* m = (float*)ptrs[2 * n_tensors + ti];
   float* v = (float*)ptrs[3 * n_tensors + ti];
-  const float lr = hyper[0], bc1 = hyper[1], bc2 = hyper[2], gs = hyper[3];
+  const float lr = hyper ? hyper[0] : lr_v, bc1 = hyper ? hyper[1] : bc1_v, bc2 = hyper ? hyper[2] : bc2_v,
+              gs = hyper ? hyper[3] : gs_v;
   const float step_size = lr / bc1, bc2s = sqrtf(bc2);
   const int64_t end = (start + 4096 < n) ? start + 4096 : n;
   for (int64_t i = start + threadIdx.x; i < end; i += 256) {
@@ -339,40 +341,54 @@ inline int grid_for(size_t total) {
 
 }  // namespace
 
+// Both entry points below run the same two kernels; they differ only in where the 8 floats of
+// partial sums per chunk live.
+static int loss_launch(const int64_t* tokens, const float* logits, int ldl, const float* weights, const float* pred_len,
+                       const float* mu, const float* logvar, const float* pred_prop, const float* true_prop,
+                       const int64_t* true_len, float beta, int B, int L, int n_cls, int n_len, int d_latent, int pad_idx,
+                       int n_groups, float* out5, float* dlogits, float* dpred_len, float* dmu, float* dlogvar,
+                       float* dpred_prop, float* sums, hipStream_t s, const char* who) {
+  TVAE_CHECK(tokens && logits && weights && pred_len && mu && logvar && out5 && sums, TVAE_E_NULL, "%s: null pointer", who);
+  TVAE_CHECK(B > 0 && L > 0 && n_cls > 0 && n_cls <= ldl && n_len > 0 && d_latent > 0, TVAE_E_SHAPE,
+             "%s: bad shape B=%d L=%d n_cls=%d ldl=%d", who, B, L, n_cls, ldl);
+  TVAE_CHECK(!pred_prop || true_prop, TVAE_E_NULL, "%s: pred_prop without true_prop", who);
+  TVAE_CHECK((dmu == nullptr) == (dlogvar == nullptr), TVAE_E_NULL, "%s: dmu/dlogvar must come together", who);
+  TVAE_CHECK(n_groups >= 1 && B % n_groups == 0, TVAE_E_SHAPE, "%s: B=%d not divisible into %d groups", who, B, n_groups);
+  if (hipMemsetAsync(sums, 0, 8 * (size_t)n_groups * sizeof(float), s) != hipSuccess) {
+    tvae_set_error("%s: memset failed", who);
+    return TVAE_E_LAUNCH;
+  }
+  LossArgs a = {tokens, logits, ldl, weights, pred_len, mu, logvar, pred_prop, true_prop, true_len, beta,
+                B, L, n_cls, n_len, d_latent, pad_idx, n_groups, out5, dlogits, dpred_len, dmu, dlogvar, dpred_prop, sums};
+  dim3 grid(cdiv((long)(B / n_groups) * L, 256), n_groups);
+  hipLaunchKernelGGL(loss_reduce_kernel, grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL(loss_grad_kernel, grid, dim3(256), 0, s, a);
+  TVAE_LAUNCH_CHECK(who);
+  return TVAE_OK;
+}
+
 extern "C" int tvae_loss_fwd_bwd(const int64_t* tokens, const float* logits, int ldl, const float* weights,
                                  const float* pred_len, const float* mu, const float* logvar, const float* pred_prop,
                                  const float* true_prop, const int64_t* true_len, float beta, int B, int L, int n_cls, int n_len, int d_latent,
                                  int pad_idx, int n_groups, float* out5, float* dlogits, float* dpred_len, float* dmu, float* dlogvar,
                                  float* dpred_prop, float* scratch, void* stream) {
-  TVAE_CHECK(tokens && logits && weights && pred_len && mu && logvar && out5 && scratch, TVAE_E_NULL,
-             "tvae_loss_fwd_bwd: null pointer");
-  TVAE_CHECK(B > 0 && L > 0 && n_cls > 0 && n_cls <= ldl && n_len > 0 && d_latent > 0, TVAE_E_SHAPE,
-             "tvae_loss_fwd_bwd: bad shape B=%d L=%d n_cls=%d ldl=%d", B, L, n_cls, ldl);
-  TVAE_CHECK(!pred_prop || true_prop, TVAE_E_NULL, "tvae_loss_fwd_bwd: pred_prop without true_prop");
-  TVAE_CHECK((dmu == nullptr) == (dlogvar == nullptr), TVAE_E_NULL, "tvae_loss_fwd_bwd: dmu/dlogvar must come together");
-  hipStream_t s = (hipStream_t)stream;
-  TVAE_CHECK(n_groups >= 1 && B % n_groups == 0, TVAE_E_SHAPE, "tvae_loss_fwd_bwd: B=%d not divisible into %d groups", B, n_groups);
-  if (hipMemsetAsync(scratch, 0, 8 * n_groups * sizeof(float), s) != hipSuccess) {
-    tvae_set_error("tvae_loss_fwd_bwd: memset failed");
-    return TVAE_E_LAUNCH;
-  }
-  LossArgs a = {tokens, logits, ldl, weights, pred_len, mu, logvar, pred_prop, true_prop, true_len, beta,
-                B, L, n_cls, n_len, d_latent, pad_idx, n_groups, out5, dlogits, dpred_len, dmu, dlogvar, dpred_prop, scratch};
-  dim3 grid(cdiv((long)(B / n_groups) * L, 256), n_groups);
-  hipLaunchKernelGGL(loss_reduce_kernel, grid, dim3(256), 0, s, a);
-  hipLaunchKernelGGL(loss_grad_kernel, grid, dim3(256), 0, s, a);
-  TVAE_LAUNCH_CHECK("tvae_loss_fwd_bwd");
-  return TVAE_OK;
+  return loss_launch(tokens, logits, ldl, weights, pred_len, mu, logvar, pred_prop, true_prop, true_len, beta, B, L, n_cls,
+                     n_len, d_latent, pad_idx, n_groups, out5, dlogits, dpred_len, dmu, dlogvar, dpred_prop, scratch,
+                     (hipStream_t)stream, "tvae_loss_fwd_bwd");
 }
 
 extern "C" int tvae_adam_multi(void* const* ptrs, const int64_t* sizes, const int32_t* chunk_tensor,
                                const int64_t* chunk_start, int n_tensors, int n_chunks, const float* hyper,
-                               float beta1, float beta2, float eps, int zero_grad, void* stream) {
-  TVAE_CHECK(ptrs && sizes && chunk_tensor && chunk_start && hyper, TVAE_E_NULL, "tvae_adam_multi: null pointer");
+                               double lr, double bias_correction1, double bias_correction2, double grad_scale,
+                               double beta1, double beta2, double eps, int zero_grad, void* stream) {
+  TVAE_CHECK(ptrs && sizes && chunk_tensor && chunk_start, TVAE_E_NULL, "tvae_adam_multi: null pointer");
+  TVAE_CHECK(hyper || (bias_correction1 > 0.0 && bias_correction2 > 0.0), TVAE_E_SHAPE,
+             "tvae_adam_multi: bias corrections must be positive (step >= 1), got %g %g", bias_correction1, bias_correction2);
   TVAE_CHECK(n_tensors > 0 && n_chunks > 0, TVAE_E_SHAPE, "tvae_adam_multi: empty parameter list");
-  float omb1 = (float)(1.0 - (double)beta1), omb2 = (float)(1.0 - (double)beta2);
+  float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
   hipLaunchKernelGGL(adam_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, ptrs, sizes, chunk_tensor,
-                     chunk_start, n_tensors, hyper, beta2, omb1, omb2, eps, zero_grad);
+                     chunk_start, n_tensors, hyper, (float)lr, (float)bias_correction1, (float)bias_correction2,
+                     (float)grad_scale, (float)beta2, omb1, omb2, (float)eps, zero_grad);
   TVAE_LAUNCH_CHECK("tvae_adam_multi");
   return TVAE_OK;
 }

@@ -8,6 +8,7 @@ query projection -> one-query attention over the PRE-PROJECTED memory keys/value
 The arithmetic per position is the same as the reference's (causal masking makes position i
 independent of later positions), which is what makes the token sequences bit-identical.
 """
+import collections
 import math
 
 import torch
@@ -17,6 +18,13 @@ from .ops import _p, _stream, call
 
 
 GRAPH_MAX_N = 2048      # latent batches up to this size are launch-bound: their step loop is replayed as a HIP graph
+GRAPH_CACHE_MAX = 4     # captured graphs kept per model (least recently used goes first): a graph owns its K/V caches,
+#                         ~1.5 MB per latent for trans4x-256, so an unbounded cache grows by GBs with every new batch size
+
+
+def clear_decode_graphs(model):
+    "drop every captured decode graph of `model` (and the HBM their private pools hold)"
+    model.__dict__.pop("_tvae_decode_graphs", None)
 
 
 def _weights_stamp(model):
@@ -47,16 +55,21 @@ class GreedyDecoder:
         if n > GRAPH_MAX_N or not torch.cuda.is_available():
             return self._steps(mem, key_mask, None, start_id, cond_ids, max_len)[:, 1:]
         key = (n, tuple(mem.shape), cond_ids, int(start_id), max_len, z.device.index)
-        cache = model.__dict__.setdefault("_tvae_decode_graphs", {})
+        cache = model.__dict__.setdefault("_tvae_decode_graphs", {"graphs": collections.OrderedDict(), "seen": {}})
+        graphs, seen = cache["graphs"], cache["seen"]
         stamp = _weights_stamp(model)
-        entry = cache.get(key)
+        entry = graphs.get(key)
         if entry is not None and entry["stamp"] != stamp:
-            del cache[key]                                    # weights moved since the capture: take it again
+            del graphs[key]                                   # weights moved since the capture: take it again
             entry = None
         if entry is None:
-            if cache.get(("seen", key)) != stamp:             # first call with this shape: plain launches
-                cache[("seen", key)] = stamp
+            if seen.get(key) != stamp:                        # first call with this shape: plain launches
+                if len(seen) > 64:
+                    seen.clear()
+                seen[key] = stamp
                 return self._steps(mem, key_mask, None, start_id, cond_ids, max_len)[:, 1:]
+            while len(graphs) >= GRAPH_CACHE_MAX:
+                graphs.popitem(last=False)                    # least recently used graph and its pool
             entry = {"stamp": stamp, "mem": torch.empty_like(mem), "mask": torch.empty_like(key_mask),
                      "ids": torch.empty((n, max_len + 1), dtype=torch.int64, device=z.device)}
             entry["mem"].copy_(mem)
@@ -65,7 +78,8 @@ class GreedyDecoder:
             with torch.cuda.graph(graph):
                 self._steps(entry["mem"], entry["mask"], entry["ids"], start_id, cond_ids, max_len)
             entry["graph"] = graph
-            cache[key] = entry
+            graphs[key] = entry
+        graphs.move_to_end(key)
         entry["mem"].copy_(mem)
         entry["mask"].copy_(key_mask)
         entry["graph"].replay()

@@ -18,13 +18,26 @@ from ._lib import (F32, BF16, F32X3, GEMM_B_SPLIT3, GEMM_RELU, GEMM_ACCUM, GEMM_
 # ----------------------------------------------------------------------------- configuration
 _DTYPES = {"fp32": F32, "f32": F32, "f32x3": F32X3, "bf16": BF16}
 # TVAE_COMPUTE_DTYPE picks the GEMM arithmetic at import (default: exact fp32 MFMA)
-_state = {"dtype": _DTYPES[os.environ.get("TVAE_COMPUTE_DTYPE", "fp32")], "site": 0}
+_state = {"dtype": _DTYPES[os.environ.get("TVAE_COMPUTE_DTYPE", "fp32")], "site": 0, "wgrad": None, "dgrad": None}
+# bf16 mode: arithmetic of the weight-gradient / data-gradient products (None = bf16 like the forward)
+_BF16_ROLES = {"wgrad": os.environ.get("TVAE_BF16_WGRAD"), "dgrad": os.environ.get("TVAE_BF16_DGRAD")}
 
 
-def set_compute_dtype(name):
+def set_compute_dtype(name, wgrad=None, dgrad=None):
     """GEMM arithmetic: 'fp32' (exact, v_mfma_f32_32x32x2_f32), 'f32x3' (fp32-accurate: six bf16 MFMAs
-    on exact 3-way bf16 splits of the operands) or 'bf16' (operands rounded to bf16, fp32 accumulate)."""
+    on exact 3-way bf16 splits of the operands) or 'bf16' (operands rounded to bf16, fp32 accumulate).
+    In 'bf16' mode the weight-gradient and data-gradient products may run in another arithmetic
+    (`wgrad` / `dgrad` = 'f32x3' | 'fp32' | None; default from TVAE_BF16_WGRAD / TVAE_BF16_DGRAD)."""
     _state["dtype"] = _DTYPES[name]
+    _state["wgrad"] = _state["dgrad"] = None
+    if _state["dtype"] == BF16:
+        for role, given in (("wgrad", wgrad), ("dgrad", dgrad)):
+            pick = given if given is not None else _BF16_ROLES[role]
+            _state[role] = _DTYPES[pick] if pick else None
+
+
+def _role_dtype(role):
+    return _state[role] if _state[role] is not None else _state["dtype"]
 
 
 def compute_dtype():
@@ -37,6 +50,16 @@ def next_site():
 
 
 _rng = {}
+# Dropout randomness.  A keep decision is a hash of (seed, step, site, element):
+#   seed, step  device uint32[2] per GPU (below): the kernels read them when they RUN, so they may only change between a
+#               forward and ITS backward never -- VAEShell.train_step bumps `step` after the optimizer step;
+#   site        16 bits of call-site id (one per dropout module) | 16 bits of `pass`, a host counter that
+#               EncoderDecoder.encode bumps on every training-mode forward.  The Drop object made in the forward carries
+#               the combined number into the backward, so a plain `loss.backward()` loop over vae.model (no train_step),
+#               and the unfused chunk loop, draw fresh masks on every forward all the same.
+# Nothing here follows torch.manual_seed by itself: VAEShell.train seeds from torch.initial_seed() + rank unless
+# seed_rng was called explicitly, and rng_snapshot / rng_restore carry {seed, step, pass} through a checkpoint.
+_pass = {"n": 0, "explicit_seed": False}
 
 
 def rng_state(device):
@@ -47,9 +70,31 @@ def rng_state(device):
     return _rng[key]
 
 
-def seed_rng(device, seed):
+def seed_rng(device, seed, step=0, n_pass=0, explicit=True):
+    "seed the dropout stream of `device` (and restart the pass counter): same seed, same masks"
     st = rng_state(device)
-    st.copy_(torch.tensor([seed & 0x7FFFFFFF, 0], dtype=torch.int32))
+    st.copy_(torch.tensor([seed & 0x7FFFFFFF, step & 0x7FFFFFFF], dtype=torch.int32))
+    _pass["n"] = int(n_pass)
+    _pass["explicit_seed"] = bool(explicit)
+
+
+def seeded_explicitly():
+    return _pass["explicit_seed"]
+
+
+def next_pass():
+    "a new training-mode forward pass begins: its dropout sites draw masks of their own"
+    _pass["n"] = (_pass["n"] + 1) & 0xFFFF
+
+
+def rng_snapshot(device):
+    "{seed, step, pass} as plain ints (synchronises: checkpoint time only)"
+    seed, step = (int(v) for v in rng_state(device).cpu().tolist())
+    return {"seed": seed, "step": step, "pass": _pass["n"]}
+
+
+def rng_restore(device, snap):
+    seed_rng(device, int(snap["seed"]), int(snap.get("step", 0)), int(snap.get("pass", 0)))
 
 
 def advance_rng(device):
@@ -67,7 +112,7 @@ class Drop:
     def make(p, site, training, device):
         if not training or p <= 0.0:
             return None
-        return Drop(p, site, rng_state(device))
+        return Drop(p, (site & 0xFFFF) | (_pass["n"] << 16), rng_state(device))
 
 
 def _drop_args(drop):
@@ -185,9 +230,9 @@ def weights_changed():
     _weights_epoch[0] += 1
 
 
-def _split_weight(W):
+def _split_weight(W, dtype=None):
     """(planes of W (N, 3K), planes of W^T (K, 3N)) as int16 tensors, or None if W does not qualify."""
-    if _state["dtype"] != F32X3 or not isinstance(W, torch.nn.Parameter) or W.dim() != 2 or not W.is_contiguous():
+    if (_state["dtype"] if dtype is None else dtype) != F32X3 or not isinstance(W, torch.nn.Parameter) or W.dim() != 2 or not W.is_contiguous():
         return None
     N, K = W.shape
     if N % 8 or K % 8:
@@ -235,13 +280,14 @@ def linear_dgrad(dy, W, out=None, accumulate=False, relumask=None, alpha=1.0, a_
         flags |= GEMM_A_DROPMASK
     if relumask is not None:
         flags |= GEMM_RELUMASK
-    sp = _split_weight(W) if dy.stride(0) % 4 == 0 else None
+    dt = _role_dtype("dgrad")
+    sp = _split_weight(W, dt) if dy.stride(0) % 4 == 0 else None
     if sp is not None:                     # W^T pre-split: the contraction index (out features) is contiguous
         Bm, ldb, flags = sp[1], 3 * N, flags | GEMM_B_SPLIT3
     else:
         Bm, ldb, flags = W, W.stride(0), flags | GEMM_B_KMAJOR
     gemm(dy, dy.stride(0), Bm, ldb, out, out.stride(0), M, K, N, residual=relumask,
-         ldr=0 if relumask is None else relumask.stride(0), alpha=alpha, flags=flags, drop=a_drop)
+         ldr=0 if relumask is None else relumask.stride(0), alpha=alpha, flags=flags, drop=a_drop, dtype=dt)
     return out
 
 
@@ -258,8 +304,11 @@ def linear_wgrad(dy, x, a_drop=None, want_bias=True, W=None, b=None):
     else:
         dW = torch.zeros((N, K), device=dy.device, dtype=torch.float32)
         db = torch.zeros((N,), device=dy.device, dtype=torch.float32) if want_bias else None
+    dt = _role_dtype("wgrad")
+    if dt == F32X3 and a_drop is not None:         # the 3xbf16 kernel cannot regenerate the mask of a k-major operand
+        dy, a_drop = masked_grad(dy, a_drop, force=True)
     flags = GEMM_A_KMAJOR | GEMM_B_KMAJOR | GEMM_SPLITK | (GEMM_A_DROPMASK if a_drop is not None else 0)
-    gemm(dy, dy.stride(0), x, x.stride(0), dW, K, N, K, M, flags=flags, drop=a_drop, a_rowsum=db)
+    gemm(dy, dy.stride(0), x, x.stride(0), dW, K, N, K, M, flags=flags, drop=a_drop, a_rowsum=db, dtype=dt)
     if direct:
         _sink[0].done(W)
         if want_bias:
@@ -628,7 +677,7 @@ def _conv_wgrad(dy_rows, xin, rows_total, Cin, Cout, k):
     dwp = torch.zeros((Cout, k * Cin), device=xin.device, dtype=torch.float32)
     db = torch.zeros((Cout,), device=xin.device, dtype=torch.float32)     # bias grad, fused row sums
     gemm(dy_rows, Cout, xin, Cin, dwp, k * Cin, Cout, k * Cin, rows_total - (k - 1),
-         flags=GEMM_A_KMAJOR | GEMM_B_KMAJOR | GEMM_SPLITK, a_rowsum=db)
+         flags=GEMM_A_KMAJOR | GEMM_B_KMAJOR | GEMM_SPLITK, a_rowsum=db, dtype=_role_dtype("wgrad"))
     return dwp, db
 
 
@@ -636,7 +685,7 @@ def _conv_dgrad(dy_padded, rows_total, Cout, w_dgrad, Cin, k):
     """dx[u, ci] = sum_j dy[u-j, :] . w[:, ci, j]: a conv-as-GEMM over the gradient rows.
     dy_padded is ((k-1) + rows_total, Cout) with k-1 leading zero rows; w_dgrad is (Cin, k*Cout)."""
     dx = torch.empty((rows_total, Cin), device=dy_padded.device, dtype=torch.float32)
-    gemm(dy_padded, Cout, w_dgrad, k * Cout, dx, Cin, rows_total, Cin, k * Cout)
+    gemm(dy_padded, Cout, w_dgrad, k * Cout, dx, Cin, rows_total, Cin, k * Cout, dtype=_role_dtype("dgrad"))
     return dx
 
 
@@ -805,12 +854,12 @@ class LossFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------- Adam
-def masked_grad(dy2, drop):
+def masked_grad(dy2, drop, force=False):
     """(gradient operand, a_drop) for the two GEMMs that consume the gradient of a dropped-out
     output.  fp32 / bf16 kernels regenerate the keep-mask while staging (a_drop); the f32x3 kernel
     stages a k-major operand one row at a time, across the mask's hash groups, so there the mask is
     applied once by an elementwise pass and both GEMMs read the product."""
-    if drop is None or _state["dtype"] != F32X3:
+    if drop is None or not (force or F32X3 in (_state["dtype"], _state["wgrad"], _state["dgrad"])):
         return dy2, drop
     out = torch.empty_like(dy2)
     r, s, p = _drop_args(drop)
@@ -828,8 +877,7 @@ class FusedAdam:
         self.betas, self.eps = betas, eps
         self.exp_avg = [torch.zeros_like(p) for p in self.params]
         self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
-        self.hyper = torch.zeros(4, device=dev, dtype=torch.float32)
-        self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(4)
+        self._hyper = (0.0, 1.0, 1.0, 1.0)           # lr, bias corrections, grad scale of the NEXT launch
         sizes = [p.numel() for p in self.params]
         ct, cs = [], []
         for i, n in enumerate(sizes):
@@ -857,17 +905,16 @@ class FusedAdam:
         return self._ptrs
 
     def set_hyper(self, lr, step, grad_scale=1.0):
+        """Numbers of the next launch.  They travel BY VALUE in the launch itself: the host queues steps ahead of
+        the GPU (train() reads losses two steps late, bench.py never syncs between steps), so a device or pinned
+        buffer rewritten per step would hand step t the learning rate of step t+1 or t+2."""
         b1, b2 = self.betas
-        self._hyper_host[0] = lr
-        self._hyper_host[1] = 1.0 - b1 ** step
-        self._hyper_host[2] = 1.0 - b2 ** step
-        self._hyper_host[3] = grad_scale
-        self.hyper.copy_(self._hyper_host, non_blocking=True)
+        self._hyper = (float(lr), 1.0 - b1 ** step, 1.0 - b2 ** step, float(grad_scale))
 
     def launch(self, zero_grad=False):
         ptrs = self._ptr_table()
         call("tvae_adam_multi", _p(ptrs), _p(self.sizes), _p(self.chunk_tensor), _p(self.chunk_start),
-             len(self.params), self.n_chunks, _p(self.hyper), self.betas[0], self.betas[1], self.eps,
+             len(self.params), self.n_chunks, None, *self._hyper, self.betas[0], self.betas[1], self.eps,
              int(zero_grad), _stream())
         weights_changed()
 

@@ -119,9 +119,13 @@ class DataParallel:
         from . import ops
         self.sink = ops.GradSink(on_complete=self._hook if overlap else None)
         self._seen = set()
+        self._handles = []
+        self.closed = False
+        self.timing = False              # bench.py: record an event pair around the waits of finish()
+        self.wait_events = []
         if overlap:
             for p in self.arena.params:
-                p.register_post_accumulate_grad_hook(self._autograd_hook)
+                self._handles.append(p.register_post_accumulate_grad_hook(self._autograd_hook))
         # parameters start identical on every rank
         for p in vae.model.parameters():
             _broadcast(p.data, src=0)
@@ -130,6 +134,19 @@ class DataParallel:
 
     def _set_grad_scale(self, s):
         self.vae.optimizer.optimizer.grad_scale = s
+
+    def close(self):
+        """Detach from the shell: autograd hooks removed, the optimizer's gradient scale back to 1.  The parameters'
+        .grad stay views of the arena (harmless: a later single-process step accumulates into them as into any
+        buffer).  A closed engine must not be stepped again; VAEShell._data_parallel builds a new one."""
+        if self.closed:
+            return
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+        self.sink.on_complete = None
+        self._set_grad_scale(1.0)
+        self.closed = True
 
     def _autograd_hook(self, p):
         # autograd runs the post-accumulate hook of EVERY parameter it visits, including those whose
@@ -170,10 +187,19 @@ class DataParallel:
         for bi in range(len(self.arena.buckets)):
             if bi not in self._launched:                  # not launched from a hook (or overlap off)
                 self._launch(bi)
+        ev = None
+        if self.timing and self.arena.flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for w in self._pending:
-            w.wait()
+            w.wait()                      # RCCL: the compute stream waits for the collective's stream, the host does not
+        if ev is not None:
+            ev[1].record()
+            self.wait_events.append(ev)
         self._armed = False
         self._pending = []
 
     def step(self, data, beta, eps=None):
+        if self.closed:
+            raise RuntimeError("DataParallel.step on a closed engine")
         return self.vae.train_step(data, beta, eps=eps, dp=self)

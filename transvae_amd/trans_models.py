@@ -423,6 +423,8 @@ class EncoderDecoder(nn.Module):
         return x, mu, logvar, pred_len, prop
 
     def encode(self, src, src_mask, eps=None):
+        if self.training:
+            ops.next_pass()              # fresh dropout masks for every training-mode forward
         return self.encoder(self.src_embed(src), src_mask, eps)
 
     def decode(self, mem, src_mask, tgt, tgt_mask):
@@ -620,6 +622,18 @@ class VAEShell():
             ops.advance_rng(dev)
         return table
 
+    def _data_parallel(self):
+        "the shell's DataParallel engine: one per shell, rebuilt only when the world size changes"
+        import torch.distributed as dist
+        from .parallel import DataParallel
+        dp = getattr(self, '_dp', None)
+        if dp is not None and (dp.closed or dp.world != dist.get_world_size()):
+            dp.close()
+            dp = None
+        if dp is None:
+            dp = self._dp = DataParallel(self)
+        return dp
+
     @torch.no_grad()
     def eval_step(self, data, beta):
         "Forward + loss on a batch without gradients (the reference's validation pass, :267-307)"
@@ -639,6 +653,13 @@ class VAEShell():
         "Train and validate (reference :126-352: same batching, CSV log rows and checkpoint cadence)"
         train_data = self.data_gen(train_mols, train_props, char_dict=self.params['CHAR_DICT'])
         val_data = self.data_gen(val_mols, val_props, char_dict=self.params['CHAR_DICT'])
+        # targets are ids 1 .. vocab-1 shifted down by one (loss.py:26); F.cross_entropy of the reference raises on
+        # anything else, the loss kernel would give it zero weight: refuse bad vocabularies / data once, here
+        for what, d in (('train', train_data), ('validation', val_data)):
+            ids = d[:, 1:self.src_len + 1]
+            if ids.numel() and (float(ids.min()) < 1 or float(ids.max()) > self.vocab_size - 1):
+                raise IndexError("Target {} is out of bounds. ({} data: token ids after <start> must lie in 1..{})".format(
+                    int(ids.min() if float(ids.min()) < 1 else ids.max()) - 1, what, self.vocab_size - 1))
         # one process per GPU (torch.distributed initialised by the launcher): every rank takes its own
         # shard of each epoch's shuffle and BATCH_SIZE is per rank; rank 0 logs and writes checkpoints
         import torch.distributed as dist
@@ -647,8 +668,16 @@ class VAEShell():
         dp = None
         if world > 1:
             from .parallel import DataParallel, mean_over_ranks
-            dp = DataParallel(self)
+            dp = self._data_parallel()
             log, save = log and rank == 0, save and rank == 0
+        # dropout stream: continue the one a checkpoint carried, else follow torch's seed (+ rank, so that the replicas
+        # of a data-parallel run do not all drop the same units) unless the caller seeded it (ops.seed_rng)
+        if self.current_state['params'].get('RNG_STATE') is not None and self.loaded_from is not None \
+                and not getattr(self, '_rng_resumed', False):
+            ops.rng_restore(self._device(), self.current_state['params']['RNG_STATE'])
+            self._rng_resumed = True
+        elif not ops.seeded_explicitly():
+            ops.seed_rng(self._device(), (torch.initial_seed() + rank) & 0x7FFFFFFF, explicit=False)
 
         # the encoded molecules move to HBM once (one byte per token); a batch is one gather launch in the
         # order the reference's DataLoader (or a DistributedSampler) would have produced (data.DeviceLoader)
@@ -717,6 +746,10 @@ class VAEShell():
             self.n_epochs += 1
             print('Epoch - {} Train - {} Val - {} KLBeta - {}'.format(self.n_epochs, train_loss, val_loss, beta))
             self.current_state['epoch'] = self.n_epochs
+            snap = ops.rng_snapshot(self._device())                          # a resumed run continues the mask stream
+            self.params['RNG_STATE'] = snap
+            if isinstance(self.current_state.get('params'), dict):           # after load() this is the LOADED dict
+                self.current_state['params']['RNG_STATE'] = snap
             self.current_state['model_state_dict'] = self.model.state_dict()
             self.optimizer.sync_state_dict()
             self.current_state['optimizer_state_dict'] = self.optimizer.state_dict
@@ -727,6 +760,8 @@ class VAEShell():
                     self.save(self.current_state, 'best')
             if (self.n_epochs) % save_freq == 0 and save:
                 self.save(self.current_state, str(self.n_epochs).zfill(3))
+        if dp is not None:
+            dp.close()          # hooks off, grad_scale back to 1: a later single-process train_step is unscaled
 
     # ------------------------------------------------------------------ sampling / decoding
     def sample_from_memory(self, size, mode='rand', sample_dims=None, k=5):

@@ -216,6 +216,26 @@ int tvae_loss_fwd_bwd(const int64_t* tokens, const float* logits, int ldl, const
                       float* dpred_prop, float* scratch, void* stream);
 
 /*
+ * The same computation for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE: it exists only for those callers.  The
+ * partial sums that tvae_loss_fwd_bwd keeps in the caller's `scratch` live here in a device array built into
+ * the library (8 floats per chunk, TVAE_LOSS_STATIC_MAX_GROUPS chunks = 32 KB on every GPU the library runs
+ * on, held until the process ends); the call allocates nothing and frees nothing, n_groups beyond the maximum
+ * is refused with TVAE_E_SHAPE.  Every call on a GPU shares that GPU's array (it is cleared on `stream` at the
+ * start of each call), so two calls that overlap on ONE GPU -- different streams, or different threads -- race;
+ * calls on one stream, or on different GPUs, do not.  The device that is current at the call must be the one
+ * `stream` and the buffers belong to.
+ */
+#define TVAE_LOSS_STATIC_MAX_GROUPS 1024
+int tvae_loss_fwd_bwd_static(const int64_t* tokens, const float* logits, int ldl, const float* weights,
+                             const float* pred_len, const float* mu, const float* logvar,
+                             const float* pred_prop, const float* true_prop, const int64_t* true_len,
+                             float beta,
+                             int B, int L, int n_cls, int n_len, int d_latent, int pad_idx, int n_groups,
+                             float* out5, float* dlogits, float* dpred_len, float* dmu, float* dlogvar,
+                             float* dpred_prop, void* stream);
+
+/*
  * Fused multi-tensor Adam (torch.optim.Adam as built at transvae/trans_models.py:703-705,
  * driven by NoamOpt.step transvae/opt.py:21-30 or AdamOpt :47-49).
  *   ptrs: device array of 4*n_tensors pointers laid out [p_0..][g_0..][m_0..][v_0..]

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("TVAE_LIB_PATH") or os.path.join(_HERE, "lib", "libtva
 F32, BF16, F32X3 = 0, 1, 2
 GEMM_RELU, GEMM_ACCUM, GEMM_A_KMAJOR, GEMM_B_KMAJOR, GEMM_SPLITK, GEMM_A_DROPMASK, GEMM_RELUMASK = 1, 2, 4, 8, 16, 32, 64
 GEMM_B_SPLIT3 = 128
+LOSS_STATIC_MAX_GROUPS = 1024
 
 _vp, _i, _f, _u, _i64, _d = C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_int64, C.c_double
 
@@ -41,6 +42,8 @@ SIGNATURES = {
     "tvae_reparam_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _f, _vp],
     "tvae_loss_fwd_bwd": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i, _i,
                           _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "tvae_loss_fwd_bwd_static": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i, _i,
+                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "tvae_adam_multi": [_vp, _vp, _vp, _vp, _i, _i, _vp, _d, _d, _d, _d, _d, _d, _d, _i, _vp],
     "tvae_decode_attn": [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp],
     "tvae_argmax_next": [_vp, _i, _i, _vp, _i, _i, _i, _vp],

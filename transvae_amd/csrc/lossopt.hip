@@ -1,6 +1,7 @@
 // trans_vae_loss fused forward+backward, multi-tensor Adam, and the single-token kernels of the
 // KV-cached greedy decoder.  All HBM-bound.
 #include "common.h"
+#include <mutex>
 
 namespace {
 
@@ -375,6 +376,53 @@ extern "C" int tvae_loss_fwd_bwd(const int64_t* tokens, const float* logits, int
   return loss_launch(tokens, logits, ldl, weights, pred_len, mu, logvar, pred_prop, true_prop, true_len, beta, B, L, n_cls,
                      n_len, d_latent, pad_idx, n_groups, out5, dlogits, dpred_len, dmu, dlogvar, dpred_prop, scratch,
                      (hipStream_t)stream, "tvae_loss_fwd_bwd");
+}
+
+// ---- the same call for callers that cannot allocate (HIP graph capture, serving loops): the partial sums live in
+// a device array that is part of the code object, TVAE_LOSS_STATIC_MAX_GROUPS chunks at most (32 KB per GPU, held
+// until the process ends).  `scratch` is a host-side stand-in for that array, NOT a device address: its address on
+// each GPU comes from hipGetSymbolAddress with that GPU current, once per device, and only that pointer is ever
+// given to a memset or a kernel.
+static __device__ __align__(256) float scratch[8 * TVAE_LOSS_STATIC_MAX_GROUPS];
+static constexpr int MAX_DEVICES = 64;
+static float* g_static_sums[MAX_DEVICES];          // per device: where `scratch` lives on it
+static std::mutex g_static_sums_lock;
+
+static int static_sums_for_current_device(float** out, const char* who) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) {
+    tvae_set_error("%s: no current HIP device (or device index beyond %d)", who, MAX_DEVICES - 1);
+    return TVAE_E_LAUNCH;
+  }
+  std::lock_guard<std::mutex> hold(g_static_sums_lock);
+  if (!g_static_sums[dev]) {
+    float* p = nullptr;
+    hipError_t e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !p) {
+      tvae_set_error("%s: hipGetSymbolAddress(scratch) on device %d failed: %s", who, dev, hipGetErrorString(e));
+      return TVAE_E_LAUNCH;
+    }
+    g_static_sums[dev] = p;
+  }
+  *out = g_static_sums[dev];
+  return TVAE_OK;
+}
+
+extern "C" int tvae_loss_fwd_bwd_static(const int64_t* tokens, const float* logits, int ldl, const float* weights,
+                                        const float* pred_len, const float* mu, const float* logvar, const float* pred_prop,
+                                        const float* true_prop, const int64_t* true_len, float beta, int B, int L, int n_cls,
+                                        int n_len, int d_latent, int pad_idx, int n_groups, float* out5, float* dlogits,
+                                        float* dpred_len, float* dmu, float* dlogvar, float* dpred_prop, void* stream) {
+  TVAE_CHECK(n_groups >= 1 && n_groups <= TVAE_LOSS_STATIC_MAX_GROUPS, TVAE_E_SHAPE,
+             "tvae_loss_fwd_bwd_static: n_groups=%d outside 1..%d (the built-in workspace holds %d chunks; use "
+             "tvae_loss_fwd_bwd with a caller-owned workspace beyond that)", n_groups, TVAE_LOSS_STATIC_MAX_GROUPS,
+             TVAE_LOSS_STATIC_MAX_GROUPS);
+  float* sums = nullptr;
+  int rc = static_sums_for_current_device(&sums, "tvae_loss_fwd_bwd_static");
+  if (rc != TVAE_OK) return rc;
+  return loss_launch(tokens, logits, ldl, weights, pred_len, mu, logvar, pred_prop, true_prop, true_len, beta, B, L, n_cls,
+                     n_len, d_latent, pad_idx, n_groups, out5, dlogits, dpred_len, dmu, dlogvar, dpred_prop, sums,
+                     (hipStream_t)stream, "tvae_loss_fwd_bwd_static");
 }
 
 extern "C" int tvae_adam_multi(void* const* ptrs, const int64_t* sizes, const int32_t* chunk_tensor,

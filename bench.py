@@ -64,13 +64,15 @@ def roofline_of(mode, M, N, K):
     flops = 2.0 * M * N * K
     ach = flops / tg / 1e12
     # HBM bytes per launch of this kernel and shape, from separate rocprofv3 --pmc passes
-    # (tools/pmc_traffic.sh -> profiles/r1_gemm_pmc_<mode>.json); None when no such measurement exists
+    # (tools/pmc_traffic.sh -> profiles/r<round>_gemm_pmc_<mode>.json); None when no such measurement exists
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r1_gemm_pmc_%s.json" % mode)
-    if os.path.exists(pmc):
-        rec = json.load(open(pmc))
-        if rec.get("shape") == [M, N, K]:
-            traffic = rec["traffic_bytes_per_launch"]
+    for tag in ("r2", "r1"):              # the newest measurement of this kernel and shape
+        pmc = os.path.join(ROOT, "profiles", "%s_gemm_pmc_%s.json" % (tag, mode))
+        if os.path.exists(pmc):
+            rec = json.load(open(pmc))
+            if rec.get("shape") == [M, N, K]:
+                traffic = rec["traffic_bytes_per_launch"]
+                break
     kern = {"fp32": "gemm_kernel (v_mfma_f32_32x32x2_f32)", "bf16": "gemm_kernel (v_mfma_f32_32x32x16_bf16)",
             "f32x3": "gemm3_kernel (6 x v_mfma_f32_32x32x16_bf16 per fp32 product block; peak = bf16 peak / 6)"}[mode]
     return {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[mode], "unit": "TFLOP/s",

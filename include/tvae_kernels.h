@@ -61,6 +61,7 @@ extern "C" {
 #define TVAE_GEMM_SPLITK 16     /* split K over grid.z, fp32 atomicAdd into C (C must be initialised) */
 #define TVAE_GEMM_RELUMASK 64   /* v = residual[m,n] > 0 ? v : 0 (`residual` is the saved activation, not added) */
 #define TVAE_GEMM_B_SPLIT3 128  /* dtype F32X3 only: B points at bf16 planes written by tvae_split3, ldb = 3*Kb in bf16 elements */
+#define TVAE_GEMM_B_BF16 256    /* dtype BF16 only: B points at bf16 values (N, ldb) written by tvae_cast_bf16; row-major A, K % 32 == 0 */
 #define TVAE_GEMM_A_DROPMASK 32 /* multiply A(m,k) by the dropout keep-scale of (rng, site, m*K+k): dgrad/wgrad of a dropped-out output */
 
 const char* tvae_last_error(void);
@@ -91,6 +92,14 @@ int tvae_gemm(const float* A, int lda, const float* B, int ldb, float* C, int ld
  * kernel only splits the activation operand.  Weights change once per optimizer step.
  */
 int tvae_split3(const float* w, int ldw, uint16_t* out_n, uint16_t* out_t, int rows, int cols, void* stream);
+
+/*
+ * bf16 copies of an fp32 matrix w (rows x cols, row stride ldw), round-to-nearest-even: out_n (rows, cols) and out_t
+ * (cols, rows) = w^T; either may be NULL.  Lets tvae_gemm in dtype BF16 take an nn.Linear weight as a ready bf16 B
+ * operand (TVAE_GEMM_B_BF16: forward x W^T against out_n, data gradient dY W against out_t, both in the streamed
+ * NT kernel that moves its tiles global -> LDS without touching registers).  Weights change once per optimizer step.
+ */
+int tvae_cast_bf16(const float* w, int ldw, uint16_t* out_n, uint16_t* out_t, int rows, int cols, void* stream);
 
 /* out[n] (+)= sum_m X[m*ld + n] (* dropout keep-scale if rng): bias gradients. */
 int tvae_colsum(const float* X, int ld, float* out, int M, int N, int accumulate,

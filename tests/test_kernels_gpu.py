@@ -5,6 +5,7 @@ Tolerances: fp32 kernels are exact-fp32 MFMA chains, so outputs are compared at 
 L2 (the north-star bound for loss/gradients); integer outputs are bit-exact.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -14,6 +15,8 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from helpers import rel_l2  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def dev():
@@ -516,3 +519,68 @@ def test_gemm_f32x3_is_as_accurate_as_fp32(M, N, K, presplit):
           (["%.1e" % e for e in errs["fp32"]], ["%.1e" % e for e in errs["f32x3"]]))
     for e3, e1 in zip(errs["f32x3"], errs["fp32"]):
         assert e3 < max(2.0 * e1, 3e-7), (errs)
+
+
+# ---- streamed bf16 NT kernel (LDS-DMA, weight bf16 in memory) --------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(777, 256, 256), (1500, 1024, 256), (640, 256, 1024), (130, 136, 64), (12700, 768, 256),
+                                   (50, 25 * 8, 32)])
+def test_streamed_bf16_gemm_equals_the_staged_bf16_gemm(M, N, K):
+    """Forward (bias / ReLU / residual / accumulate) and data gradient through gemm_dma.hip (nn.Parameter weight ->
+    bf16 copies of W and W^T, TVAE_GEMM_B_BF16) against (a) the register-staged bf16 kernel on the same operands (a
+    plain-tensor weight takes that path) and (b) an fp64 product of the bf16-rounded operands."""
+    from transvae_amd import ops
+    torch.manual_seed(M + N + K)
+    x = torch.randn(M, K, device=dev())
+    w = torch.randn(N, K, device=dev()) * 0.05
+    wp = torch.nn.Parameter(w.clone(), requires_grad=False)
+    b = torch.randn(N, device=dev())
+    res = torch.randn(M, N, device=dev())
+    dy = torch.randn(M, N, device=dev())
+    rb = lambda t: t.to(torch.bfloat16).double()
+    ref_f = torch.relu(rb(x) @ rb(w).t() + b.double()) + res.double()
+    ref_d = rb(dy) @ rb(w)
+    prev = ops.compute_dtype()
+    try:
+        ops.set_compute_dtype("bf16")
+        assert ops._bf16_weight(wp) is not None and ops._bf16_weight(w) is None
+        new_f = ops.linear_fwd(x, wp, b, relu=True, residual=res)
+        old_f = ops.linear_fwd(x, w, b, relu=True, residual=res)
+        assert rel_l2(new_f.cpu(), ref_f.cpu()) < 2e-6 and rel_l2(new_f.cpu(), old_f.cpu()) < 1e-6
+        acc_new = res.clone()
+        ops.gemm(x, K, ops._bf16_weight(wp)[0], K, acc_new, N, M, N, K, bias=b, flags=ops.GEMM_ACCUM | ops.GEMM_B_BF16)
+        assert rel_l2(acc_new.cpu(), (rb(x) @ rb(w).t() + b.double() + res.double()).cpu()) < 2e-6
+        if N % 32 == 0:
+            new_d = ops.linear_dgrad(dy, wp)
+            old_d = ops.linear_dgrad(dy, w)
+            assert rel_l2(new_d.cpu(), ref_d.cpu()) < 2e-6 and rel_l2(new_d.cpu(), old_d.cpu()) < 1e-6
+            # a dropped-out output's gradient: the mask is applied by a pre-pass, the result is the staged kernel's
+            ops.seed_rng(dev(), 11)
+            drop = ops.Drop(0.1, 3, ops.rng_state(dev()))
+            assert rel_l2(ops.linear_dgrad(dy, wp, a_drop=drop).cpu(), ops.linear_dgrad(dy, w, a_drop=drop).cpu()) < 1e-6
+        # the weight moves (in place, as the optimizer does): the bf16 copies follow
+        with torch.no_grad():
+            wp.mul_(1.5)
+        ops.weights_changed()
+        assert rel_l2(ops.linear_fwd(x, wp).cpu(), (rb(x) @ rb(w * 1.5).t()).cpu()) < 2e-6
+    finally:
+        ops.set_compute_dtype(prev)
+
+
+def test_streamed_fp32_gemm_switch(monkeypatch):
+    "the exact-fp32 instantiation of the streamed kernel (TVAE_GEMM_DMA=1 in a fresh process) against fp64"
+    import subprocess, sys
+    code = (
+        "import torch, sys; sys.path.insert(0, %r)\n"
+        "from transvae_amd import ops\n"
+        "torch.manual_seed(0)\n"
+        "for M, N, K in ((777, 256, 256), (1500, 1024, 256), (640, 256, 1024), (130, 136, 48)):\n"
+        "    x = torch.randn(M, K, device='cuda'); w = torch.randn(N, K, device='cuda') * 0.05; b = torch.randn(N, device='cuda')\n"
+        "    res = torch.randn(M, N, device='cuda')\n"
+        "    y = ops.linear_fwd(x, w, b, relu=True, residual=res)\n"
+        "    ref = torch.relu(x.double() @ w.double().t() + b.double()) + res.double()\n"
+        "    err = float((y.double() - ref).norm() / ref.norm())\n"
+        "    assert err < 5e-7, (M, N, K, err)\n"
+        "print('ok')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, TVAE_GEMM_DMA="1"))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-1500:]

@@ -23,9 +23,12 @@ def main():
     dev = "cuda"
     M = 63500
     rng = ops.rng_state(torch.device("cuda", 0))
-    for (N, K) in [(1024, 256), (256, 1024), (256, 256), (768, 256), (512, 256)]:
+    shapes = [(1024, 256), (256, 1024), (256, 256), (768, 256), (512, 256)]
+    if len(sys.argv) > 3:
+        shapes = [tuple(int(v) for v in sys.argv[3].split("x"))]
+    for (N, K) in shapes:
         x = torch.randn(M, K, device=dev); w = torch.nn.Parameter(torch.randn(N, K, device=dev) * 0.05); b = torch.zeros(N, device=dev)
-        y = torch.empty(M, N, device=dev); res = torch.randn(M, N, device=dev); dy = torch.randn(M, N, device=dev)
+        y = ops.rows_buffer(M, N, dev); res = torch.randn(M, N, device=dev); dy = torch.randn(M, N, device=dev)   # y: as the model allocates it
         fl = 2.0 * M * N * K
         tag = "M%d N%d K%d" % (M, N, K)
         drop = ops.Drop(0.1, 5, rng)
@@ -34,7 +37,7 @@ def main():
             bench("NT  fwd bias relu drop  " + tag, lambda: ops.linear_fwd(x, w, b, relu=True, drop=drop, out=y), fl)
             bench("NT  fwd bias drop resid " + tag, lambda: ops.linear_fwd(x, w, b, residual=res, drop=drop, out=y), fl)
         if only in ("", "nn"):
-            dx = torch.empty(M, K, device=dev)
+            dx = ops.rows_buffer(M, K, dev)
             bench("NN  dgrad               " + tag, lambda: ops.linear_dgrad(dy, w, out=dx), fl)
             bench("NN  dgrad a_drop        " + tag, lambda: ops.linear_dgrad(dy, w, out=dx, a_drop=drop), fl)
         if only in ("", "tn"):

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("TVAE_LIB_PATH") or os.path.join(_HERE, "lib", "libtva
 F32, BF16, F32X3 = 0, 1, 2
 GEMM_RELU, GEMM_ACCUM, GEMM_A_KMAJOR, GEMM_B_KMAJOR, GEMM_SPLITK, GEMM_A_DROPMASK, GEMM_RELUMASK = 1, 2, 4, 8, 16, 32, 64
 GEMM_B_SPLIT3 = 128
+GEMM_B_BF16 = 256
 LOSS_STATIC_MAX_GROUPS = 1024
 
 _vp, _i, _f, _u, _i64, _d = C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_int64, C.c_double
@@ -24,6 +25,7 @@ _vp, _i, _f, _u, _i64, _d = C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_int6
 SIGNATURES = {
     "tvae_gemm": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _f, _i, _vp, _u, _f, _vp, _i, _vp],
     "tvae_split3": [_vp, _i, _vp, _vp, _i, _i, _vp],
+    "tvae_cast_bf16": [_vp, _i, _vp, _vp, _i, _i, _vp],
     "tvae_colsum": [_vp, _i, _vp, _i, _i, _i, _vp, _u, _f, _vp],
     "tvae_layernorm_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "tvae_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],

@@ -358,6 +358,14 @@ int tile_depth(bool bf16, int tiles, bool splitk) {
 
 void tvae_gemm3_launch(const void* gp, int tiles, int splits, bool a_km, bool b_km, bool drop, bool b_split,
                        hipStream_t s);   // gemm3.hip
+void tvae_gemm_dma_launch(const void* gp, bool bf16, hipStream_t s);   // gemm_dma.hip
+
+namespace {
+bool fp32_dma_enabled() {   // TVAE_GEMM_DMA=1: exact-fp32 NT products take the LDS-DMA kernel too (experiment switch; read once)
+  static bool on = [] { const char* e = getenv("TVAE_GEMM_DMA"); return e && atoi(e) == 1; }();
+  return on;
+}
+}  // namespace
 
 extern "C" int tvae_gemm(const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                          int M, int N, int K, const float* bias, const float* residual, int ldr,
@@ -406,6 +414,22 @@ extern "C" int tvae_gemm(const float* A, int lda, const float* B, int ldb, float
   }
   const bool x3 = dtype == TVAE_F32X3 && (b_split || (aligned && !(a_km && drop)));
   int tiles = cdiv(M, BM) * cdiv(N, BN);
+  // streamed NT kernel (gemm_dma.hip): bf16 arithmetic against a weight that is bf16 in memory already, or (switch) exact fp32
+  const bool b_bf16 = flags & TVAE_GEMM_B_BF16;
+  if (b_bf16) {
+    TVAE_CHECK(dtype == TVAE_BF16 && !a_km && !b_km && !(flags & TVAE_GEMM_SPLITK) && !drop, TVAE_E_SHAPE,
+               "tvae_gemm: B_BF16 needs dtype BF16, row-major A, an n-major B, no split-K and no A-side dropout mask");
+    TVAE_CHECK(K % 32 == 0 && lda % 4 == 0 && aligned16(A) && ldb % 8 == 0 && ldb >= K && aligned16(B), TVAE_E_SHAPE,
+               "tvae_gemm: B_BF16 needs K %% 32 == 0 and 16-byte aligned rows (K %d lda %d ldb %d)", K, lda, ldb);
+  }
+  const bool dma32 = dtype == TVAE_F32 && fp32_dma_enabled() && !a_km && !b_km && !(flags & TVAE_GEMM_SPLITK) && !drop &&
+                     K % 16 == 0 && aligned;
+  if (b_bf16 || dma32) {
+    g.k_per_split = K;
+    tvae_gemm_dma_launch(&g, b_bf16, (hipStream_t)stream);
+    TVAE_LAUNCH_CHECK("tvae_gemm");
+    return TVAE_OK;
+  }
   const int BK = x3 ? 32 : tile_depth(bf16, tiles, flags & TVAE_GEMM_SPLITK);
   int splits = 1;
   if (flags & TVAE_GEMM_SPLITK) {

@@ -31,11 +31,12 @@ __device__ inline int xcd_tile_id() {
 // alpha, bias, ReLU / ReLU-mask, dropout, residual, accumulate -- or split-K atomics.  EB = row
 // segments in flight per lane in the vector path (register budget).  `lds` is the kernel's staging
 // memory (>= EPILOGUE_LDS_FLOATS floats); every wave must be past its last read of it.
-template <int EB>
+// WN = waves along n (the workgroup has 2 * WN waves, tile 128 x 64 WN; needs 2 * WN * 32 * 68 floats of LDS).
+template <int EB, int WN = 2>
 __device__ inline void gemm_epilogue(const GemmArgs& g, floatx16 (&acc)[2][2], float* lds, int m0, int n0,
                                      bool sync_first) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, hh = lane >> 5;
   const bool do_rowsum = sync_first;
   // ---- epilogue ----------------------------------------------------------------------------

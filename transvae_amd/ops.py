@@ -12,7 +12,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (F32, BF16, F32X3, GEMM_B_SPLIT3, GEMM_RELU, GEMM_ACCUM, GEMM_A_KMAJOR, GEMM_B_KMAJOR, GEMM_SPLITK,
+from ._lib import (F32, BF16, F32X3, GEMM_B_SPLIT3, GEMM_B_BF16, GEMM_RELU, GEMM_ACCUM, GEMM_A_KMAJOR, GEMM_B_KMAJOR, GEMM_SPLITK,
                    GEMM_A_DROPMASK, GEMM_RELUMASK, call)
 
 # ----------------------------------------------------------------------------- configuration
@@ -253,6 +253,29 @@ def _split_weight(W, dtype=None):
     return wn, wt
 
 
+def _bf16_weight(W, dtype=None):
+    """(bf16 copy of W (N, K), bf16 copy of W^T (K, N)) as int16 tensors for the streamed bf16 kernel, or None if W
+    does not qualify.  Made once per optimizer step (tvae_cast_bf16), kept on the parameter object."""
+    if (_state["dtype"] if dtype is None else dtype) != BF16 or not isinstance(W, torch.nn.Parameter) or W.dim() != 2 \
+            or not W.is_contiguous() or os.environ.get("TVAE_BF16_STREAM", "1") != "1":
+        return None
+    N, K = W.shape
+    if N % 8 or K % 8:
+        return None
+    stamp = (_weights_epoch[0], W._version, W.data_ptr(), N, K)
+    hit = getattr(W, "_tvae_bf16", None)
+    if hit is not None and hit[0] == stamp:
+        return hit[1], hit[2]
+    if hit is not None and hit[1].shape == (N, K) and hit[1].device == W.device:
+        wn, wt = hit[1], hit[2]
+    else:
+        wn = torch.empty((N, K), device=W.device, dtype=torch.int16)
+        wt = torch.empty((K, N), device=W.device, dtype=torch.int16)
+    call("tvae_cast_bf16", _p(W), K, _p(wn), _p(wt), N, K, _stream())
+    W._tvae_bf16 = (stamp, wn, wt)
+    return wn, wt
+
+
 def linear_fwd(x, W, b=None, relu=False, residual=None, drop=None, out=None):
     """y[M,N] = drop(relu(x W^T + b)) + residual.  x: (M,K) contiguous rows, W: (N,K)."""
     M, K = x.shape
@@ -264,6 +287,10 @@ def linear_fwd(x, W, b=None, relu=False, residual=None, drop=None, out=None):
     Bm, ldb = W, W.stride(0)
     if sp is not None:
         Bm, ldb, flags = sp[0], 3 * K, flags | GEMM_B_SPLIT3
+    elif K % 32 == 0 and x.stride(0) % 4 == 0:
+        bw = _bf16_weight(W)
+        if bw is not None:                 # streamed bf16 kernel: the weight is bf16 in memory already
+            Bm, ldb, flags = bw[0], K, flags | GEMM_B_BF16
     gemm(x, x.stride(0), Bm, ldb, out, out.stride(0), M, N, K, bias=b, residual=residual,
          ldr=0 if residual is None else residual.stride(0), flags=flags, drop=drop)
     return out
@@ -282,8 +309,14 @@ def linear_dgrad(dy, W, out=None, accumulate=False, relumask=None, alpha=1.0, a_
         flags |= GEMM_RELUMASK
     dt = _role_dtype("dgrad")
     sp = _split_weight(W, dt) if dy.stride(0) % 4 == 0 else None
+    bw = _bf16_weight(W, dt) if (sp is None and N % 32 == 0 and dy.stride(0) % 4 == 0) else None
+    if bw is not None and a_drop is not None:          # the streamed kernel copies A as it is: mask the gradient first
+        dy, a_drop = masked_grad(dy, a_drop, force=True)
+        flags &= ~GEMM_A_DROPMASK
     if sp is not None:                     # W^T pre-split: the contraction index (out features) is contiguous
         Bm, ldb, flags = sp[1], 3 * N, flags | GEMM_B_SPLIT3
+    elif bw is not None:                   # dY W as an NT product against the bf16 copy of W^T
+        Bm, ldb, flags = bw[1], N, flags | GEMM_B_BF16
     else:
         Bm, ldb, flags = W, W.stride(0), flags | GEMM_B_KMAJOR
     gemm(dy, dy.stride(0), Bm, ldb, out, out.stride(0), M, K, N, residual=relumask,
@@ -859,7 +892,8 @@ def masked_grad(dy2, drop, force=False):
     output.  fp32 / bf16 kernels regenerate the keep-mask while staging (a_drop); the f32x3 kernel
     stages a k-major operand one row at a time, across the mask's hash groups, so there the mask is
     applied once by an elementwise pass and both GEMMs read the product."""
-    if drop is None or not (force or F32X3 in (_state["dtype"], _state["wgrad"], _state["dgrad"])):
+    streamed_bf16 = _state["dtype"] == BF16 and os.environ.get("TVAE_BF16_STREAM", "1") == "1"   # copies A as it is
+    if drop is None or not (force or streamed_bf16 or F32X3 in (_state["dtype"], _state["wgrad"], _state["dgrad"])):
         return dy2, drop
     out = torch.empty_like(dy2)
     r, s, p = _drop_args(drop)

@@ -82,6 +82,49 @@ def roofline_of(mode, M, N, K):
             "launch_us": tg * 1e6, "flop_per_launch": flops}
 
 
+def decode_attn_launch(n, n_keys=63, d=256, h=4, T=126):
+    """(callable that launches the dominant decode kernel once, algorithmic bytes of that launch): the one-query attention
+    of a decode step over the self-attention K/V cache, at the mean key count of a 125-step decode.  Algorithmic bytes:
+    the n_keys cached K rows and V rows of every molecule once, plus the query and the output row."""
+    from transvae_amd import ops
+    from transvae_amd._lib import call
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ks = torch.randn(n, T, d, device=dev)
+    vs = torch.randn(n, T, d, device=dev)
+    q = torch.randn(n, 3 * d, device=dev)
+    o = torch.empty(n, d, device=dev)
+    dk = d // h
+
+    def fn():
+        call("tvae_decode_attn", ops._p(q), 3 * d, ops._p(ks), ops._p(vs), d, T, ops._p(o), d, None, 0, n_keys, n, h, dk,
+             1.0 / dk ** 0.5, ops._stream())
+    return fn, 4.0 * n * d * (2 * n_keys + 2)
+
+
+def roofline_decode_of(n):
+    "roofline object of decode_attn_kernel (HBM-bound), timed live with events on the launch stream"
+    fn, nbytes = decode_attn_launch(n)
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        fn()
+    e1.record()
+    e1.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3 / 20
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r2_decode_attn_pmc.json")
+    if os.path.exists(pmc):
+        rec = json.load(open(pmc))
+        if rec.get("shape", {}).get("n") == n:
+            traffic = rec["traffic_bytes_per_launch"]
+    return {"bound": "hbm", "achieved": nbytes / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / t / 1e9 / 8000.0,
+            "traffic": traffic, "algorithmic_bytes": nbytes, "launch_us": t * 1e6,
+            "kernel": "decode_attn_kernel<64>: one query per (molecule, head) over 63 cached fp32 K and V rows, %d molecules "
+                      "(half of the decode's device time; the other half is the fp32 MFMA GEMMs of `roofline`)" % n}
+
+
 def cpu_baseline(threads, batch=500, chunks=5):
     """The oracle's train step on host cores, as SURVEY.md 8(d) asks: batch 500 = 5 chunks of 100 molecules, each
     chunk forward + loss + backward with the gradients accumulating, then one Noam/Adam step.  Two figures: dropout
@@ -313,6 +356,8 @@ def main():
         "data_parallel": dp_report,
         "train_algorithmic_tflops": world * args.batch * FLOP_PER_MOL_FWD_BWD * args.steps / dt / 1e12,
         "train_frac_of_mfma_peak": (args.batch * FLOP_PER_MOL_FWD_BWD * args.steps / dt / 1e12) / PEAK_TFLOPS[args.dtype],
+        "train_flop_count": "algorithmic-dense: 5.940 GFLOP per molecule (SURVEY.md 8d) counts every attention tile; the kernels "
+                            "skip tiles that are provably all zero on padded molecules (attention is 8 % of the count)",
     }
 
     # ---- the same step in the other GEMM arithmetics (secondary numbers; `value` is args.dtype) -----
@@ -375,6 +420,8 @@ def main():
             return roofline_of(mode, M, N, K)
 
         out["roofline"] = roofline(args.dtype)
+        if not args.no_decode:
+            out["roofline_decode"] = roofline_decode_of(args.decode_n)
         if not args.no_extra_modes and args.dtype != "f32x3":
             out["roofline_f32x3"] = roofline("f32x3")
         ops.set_compute_dtype(args.dtype)

@@ -8,9 +8,9 @@ dt, N, K = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 kind = sys.argv[4] if len(sys.argv) > 4 else "nt"
 ops.set_compute_dtype(dt)
 M = 63500
-x = torch.randn(M, K, device="cuda"); w = torch.nn.Parameter(torch.randn(N, K, device="cuda") * 0.05, requires_grad=False);   # a weight, as in the model
- b = torch.zeros(N, device="cuda")
-y = torch.empty(M, N, device="cuda"); dy = torch.randn(M, N, device="cuda")
+x = torch.randn(M, K, device="cuda"); w = torch.nn.Parameter(torch.randn(N, K, device="cuda") * 0.05, requires_grad=False)   # a weight, as in the model
+b = torch.zeros(N, device="cuda")
+y = ops.rows_buffer(M, N, "cuda"); dy = torch.randn(M, N, device="cuda")
 for _ in range(6):
     if kind == "nt": ops.linear_fwd(x, w, b, out=y)
     elif kind == "nn": ops.linear_dgrad(dy, w)

@@ -224,27 +224,32 @@ void gemm_kernel(GemmArgs g) {
       // operand) so that only 16 fragment registers are live beside the 64 accumulators
 #pragma unroll
       for (int q = 0; q < HK / 4; ++q) {
+        // k values of this lane half in sub-step q: a 32-deep tile is walked as two 16-deep ones (k = 16 (q >> 1) +
+        // 8 hh + 4 (q & 1) ..), so the BK = 32 and BK = 16 instantiations add the products of an output element in the
+        // SAME order: which of them the host picks (it depends on M) cannot change a single bit of the result --
+        // greedy decode of a slab, of its pieces and of its rows in another order give identical tokens
+        const int kq = 16 * (q >> 1) + 8 * hh + 4 * (q & 1);
         float a[2][4], b[2][4];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int row = wm * 64 + 32 * i + r;
           if (!A_KM) {
-            float4 v = *reinterpret_cast<const float4*>(&TA[row * LDS_KC + HK * hh + 4 * q]);
+            float4 v = *reinterpret_cast<const float4*>(&TA[row * LDS_KC + kq]);
             a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;
           } else {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) a[i][s] = TA[(HK * hh + 4 * q + s) * LDS_KM + row];
+            for (int s = 0; s < 4; ++s) a[i][s] = TA[(kq + s) * LDS_KM + row];
           }
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int col = wn * 64 + 32 * j + r;
           if (!B_KM) {
-            float4 v = *reinterpret_cast<const float4*>(&TB[col * LDS_KC + HK * hh + 4 * q]);
+            float4 v = *reinterpret_cast<const float4*>(&TB[col * LDS_KC + kq]);
             b[j][0] = v.x; b[j][1] = v.y; b[j][2] = v.z; b[j][3] = v.w;
           } else {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) b[j][s] = TB[(HK * hh + 4 * q + s) * LDS_KM + col];
+            for (int s = 0; s < 4; ++s) b[j][s] = TB[(kq + s) * LDS_KM + col];
           }
         }
 #pragma unroll

@@ -214,8 +214,8 @@ constexpr float MASK_FILL = -1e9f;
 // One wave per (molecule, head): q (dk) against n_keys cached rows.  HBM-bound (the K/V rows are
 // read once per step), so the point is to read them in whole cache lines and to read nothing that
 // cannot matter:
-//   scores: 4 lanes share a key row (64 B per lane group and instruction, 16 keys per instruction),
-//           the partial dot products meet in two DPP adds;
+//   scores: 8 lanes share a key row in whole 128-byte lines (8 keys per instruction), the partial dot
+//           products meet in three DPP adds;
 //   masked keys are not read at all: their score is the -1e9 fill, and unless EVERY key of the row
 //           is masked exp(-1e9 - max) is exactly 0 in fp32, so their V rows are skipped too (an
 //           all-masked row attends uniformly to all n_keys, as in the reference, and reads them);
@@ -225,7 +225,13 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
                                                           const float* __restrict__ vc, int ldc, int Lcache,
                                                           float* __restrict__ o, int ldo, const uint8_t* __restrict__ key_mask,
                                                           int ld_mask, int n_keys, int n, int h, float scale) {
-  constexpr int NF4 = DK / 16;            // float4 per lane in the score phase
+  // scores: LPK lanes share a key row and every load instruction takes WHOLE 128-byte lines of it (dk = 64: 8 lanes x
+  // 16 bytes, twice; dk = 32: 8 lanes once) -- 64-byte pieces of 16 rows per instruction kept the address path twice as
+  // busy for the same bytes
+  constexpr int LPK = 8;                  // lanes per key row in the score phase
+  constexpr int NF4 = DK / (4 * LPK);     // float4 per lane and key (2 | 1)
+  constexpr int KPI = 64 / LPK;           // keys per load instruction (8)
+  constexpr int NG = 128 / KPI;           // key groups (16)
   constexpr int LPR = DK / 4;             // lanes per V row
   constexpr int KG = 64 / LPR;            // V rows per wave instruction
   __shared__ float ps[4][128];
@@ -233,20 +239,20 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
   const int pair = blockIdx.x * 4 + wave;
   const bool active = pair < n * h;
   const int b = active ? pair / h : 0, head = active ? pair % h : 0;
-  const int part = lane & 3, kl = lane >> 2;
+  const int part = lane & (LPK - 1), kl = lane / LPK;
   float4 qr[NF4];
 #pragma unroll
   for (int it = 0; it < NF4; ++it)
-    qr[it] = *reinterpret_cast<const float4*>(q + (size_t)b * ldq + head * DK + 16 * it + 4 * part);
+    qr[it] = *reinterpret_cast<const float4*>(q + (size_t)b * ldq + head * DK + 32 * it + 4 * part);
   const float* kbase = kc + (size_t)b * Lcache * ldc + head * DK + 4 * part;
   const uint8_t* mrow = key_mask ? key_mask + (size_t)b * ld_mask : nullptr;
-  float sc[8];
+  float sc[NG];
   float mx = -INFINITY;
 #pragma unroll
-  for (int g = 0; g < 8; ++g) {
-    const int key = 16 * g + kl;
+  for (int g = 0; g < NG; ++g) {
+    const int key = KPI * g + kl;
     float s = -INFINITY;
-    if (16 * g < n_keys) {                          // wave-uniform
+    if (KPI * g < n_keys) {                         // wave-uniform
       const bool valid = key < n_keys;
       const bool m = valid && (mrow ? mrow[key] != 0 : true);
       float acc = 0.f;
@@ -254,12 +260,13 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
         const float* kr = kbase + (size_t)key * ldc;
 #pragma unroll
         for (int it = 0; it < NF4; ++it) {
-          float4 kv = *reinterpret_cast<const float4*>(kr + 16 * it);
+          float4 kv = *reinterpret_cast<const float4*>(kr + 32 * it);
           acc += kv.x * qr[it].x + kv.y * qr[it].y + kv.z * qr[it].z + kv.w * qr[it].w;
         }
       }
       acc += __shfl_xor(acc, 1, 64);
       acc += __shfl_xor(acc, 2, 64);
+      acc += __shfl_xor(acc, 4, 64);
       if (valid) s = m ? acc * scale : MASK_FILL;
     }
     sc[g] = s;
@@ -268,14 +275,14 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
   mx = wave_max(mx);
   float loc = 0.f;
 #pragma unroll
-  for (int g = 0; g < 8; ++g) {
+  for (int g = 0; g < NG; ++g) {
     sc[g] = expf(sc[g] - mx);                       // exp(-inf) = 0 for keys past n_keys
     loc += sc[g];
   }
   const float inv = 1.f / wave_sum(part == 0 ? loc : 0.f);
   if (part == 0) {
 #pragma unroll
-    for (int g = 0; g < 8; ++g) ps[wave][16 * g + kl] = sc[g] * inv;
+    for (int g = 0; g < NG; ++g) ps[wave][KPI * g + kl] = sc[g] * inv;
   }
   __syncthreads();
   const int c4 = lane % LPR, kg = lane / LPR;

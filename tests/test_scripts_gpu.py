@@ -135,3 +135,46 @@ def test_bench_refuses_a_world_size_it_cannot_run():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True,
                        text=True, timeout=120, env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
     assert r.returncode != 0 and r.stdout.strip() == "" and "disagree" in r.stderr
+
+
+def test_config5_entropy_sampling_and_attention_dump_on_trans4x256_pubchem_pp(tmp_path, monkeypatch):
+    """BASELINE config 5 at its own size, end to end through the scripts: trans4x-256, PubChem vocabulary, property head;
+    scripts/sample.py in high_entropy and k_high_entropy modes (calc_mems -> per-dimension entropy -> top_dims / k_dims z ->
+    KV-cached greedy decode) and scripts/attention.py (forward_w_attn dump).  The checkpoint is the synthetic one."""
+    from scripts import attention, parsers, sample
+    from transvae_amd import synth
+    from transvae_amd.trans_models import TransVAE
+    monkeypatch.chdir(tmp_path)
+    cd, od, w = synth.load_vocab("pubchem")
+    vae = TransVAE(params={"CHAR_DICT": cd, "ORG_DICT": od, "CHAR_WEIGHTS": w, "BATCH_SIZE": 24, "BATCH_CHUNKS": 2},
+                   name="c5", property_predictor=True, **synth.ARCHS["trans4x-256"])
+    sd = synth.synth_state_dict(vae.model.state_dict(), 0)
+    sd["encoder.z_means.weight"] = sd["encoder.z_means.weight"] * 0.05     # latent means inside calc_entropy's (-5, 5) histogram
+    vae.model.load_state_dict(sd)
+    vae.current_state["model_state_dict"] = vae.model.state_dict()
+    vae.optimizer.sync_state_dict()
+    vae.current_state["optimizer_state_dict"] = vae.optimizer.state_dict
+    vae.save(vae.current_state, "cfg5", path="checkpoints")
+    ckpt = "checkpoints/cfg5_c5.ckpt"
+    # a loaded shell keeps the constructor's BATCH_SIZE of 500 (not an architecture parameter: reference :115-119), and
+    # calc_mems only walks FULL batches -- so, as with the reference, the --mols file needs at least 500 molecules
+    mols = [BASE[i % len(BASE)] + "C" * (i // len(BASE)) for i in range(500)]
+    pd.DataFrame(mols, columns=["mol"]).to_csv("mols.txt", index=False)
+    for mode, extra in (("high_entropy", []), ("k_high_entropy", ["--k", "5"])):
+        out = "gen_%s.csv" % mode
+        sample.sample(parsers.sample_parser().parse_args(
+            ["--model", "transvae", "--model_ckpt", ckpt, "--mols", "mols.txt", "--sample_mode", mode, "--entropy_cutoff=-1e9",
+             "--n_samples", "20", "--n_samples_per_batch", "10", "--save_path", out] + extra))
+        got = pd.read_csv(out, keep_default_na=False)
+        assert len(got) == 20 and got["mol"].map(lambda t: isinstance(t, str)).all()
+    # the z of the two modes differ in what they leave at zero: k_dims draws on exactly k dimensions
+    np.random.seed(0)
+    z = vae.sample_from_memory(6, mode="k_dims", sample_dims=list(range(128)), k=5)
+    assert int((z != 0).any(0).sum()) == 5
+    attention.calc_attention(parsers.attn_parser().parse_args(
+        ["--model", "transvae", "--model_ckpt", ckpt, "--mols", "mols.txt", "--n_samples", "24", "--batch_size", "12",
+         "--batch_chunks", "2", "--save_path", "attn5"]))
+    sa, xa = np.load("attn5_self_attn.npy"), np.load("attn5_src_attn.npy")
+    assert sa.shape == (24, 4, 4, 127, 127) and xa.shape == (24, 3, 4, 126, 127)
+    np.testing.assert_allclose(sa.sum(-1), 1.0, atol=1e-4)
+    np.testing.assert_allclose(xa.sum(-1), 1.0, atol=1e-4)

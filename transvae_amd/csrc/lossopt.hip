@@ -47,19 +47,36 @@ __device__ inline LossArgs for_group(LossArgs a, int g) {
   return a;
 }
 
+// The 256 logit rows of a workgroup are one contiguous run of 256 * ldl floats (ldl = n_cls = 25 in the model): they are
+// copied into LDS with whole-wave coalesced loads and every thread then walks ITS row there (row pitch 25 or any odd
+// number of floats: conflict-free) -- a thread walking 25 floats of a 100-byte-strided row in global memory touched 64
+// different cache lines per load instruction and the two loss kernels ran at 5-9 % of the HBM rate.
+constexpr int LOSS_STAGE_MAX = 33;          // row pitches up to this many floats are staged (256 * 33 * 4 = 33 KB)
+__device__ inline const float* stage_logit_rows(const LossArgs& a, float* tile, int row0, int rows, int tid) {
+  const int nrow = min(256, rows - row0);
+  if (a.ldl > LOSS_STAGE_MAX || nrow <= 0) return nullptr;
+  const float* src = a.logits + (size_t)row0 * a.ldl;
+  const int total = nrow * a.ldl;
+  for (int i = tid; i < total; i += 256) tile[i] = src[i];
+  __syncthreads();
+  return tile;
+}
+
 // scratch: [0] sum w[y]  [1] sum w[y]*nll  [2] sum nll_len  [3] sum (1+lv-mu^2-e^lv)  [4] sum (pp-tp)^2
 __global__ __launch_bounds__(256) void loss_reduce_kernel(LossArgs a0) {
   const LossArgs a = for_group(a0, blockIdx.y);
   __shared__ float red[4];
+  __shared__ float tile[256 * LOSS_STAGE_MAX];
   const int tid = threadIdx.x, lane = tid & 63;
   float den = 0.f, num = 0.f;
   const int rows = a.B * a.L;
   const int row = blockIdx.x * 256 + tid;
+  const float* staged = stage_logit_rows(a, tile, blockIdx.x * 256, rows, tid);
   if (row < rows) {
     int b = row / a.L, t = row % a.L;
     int y = (int)a.tokens[(size_t)b * (a.L + 1) + t + 1] - 1;
     if (y >= 0 && y < a.n_cls) {
-      const float* lg = a.logits + (size_t)row * a.ldl;
+      const float* lg = staged ? staged + tid * a.ldl : a.logits + (size_t)row * a.ldl;
       float mx = -INFINITY;
       for (int c = 0; c < a.n_cls; ++c) mx = fmaxf(mx, lg[c]);
       float se = 0.f;
@@ -132,11 +149,13 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(LossArgs a0) {
   }
   const int rows = a.B * a.L;
   const int row = blockIdx.x * 256 + tid;
+  __shared__ float tile[256 * LOSS_STAGE_MAX];
+  float* staged = a.dlogits ? const_cast<float*>(stage_logit_rows(a, tile, blockIdx.x * 256, rows, tid)) : nullptr;
   if (row < rows && a.dlogits) {
     int b = row / a.L, t = row % a.L;
     int y = (int)a.tokens[(size_t)b * (a.L + 1) + t + 1] - 1;
-    const float* lg = a.logits + (size_t)row * a.ldl;
-    float* dl = a.dlogits + (size_t)row * a.ldl;
+    const float* lg = staged ? staged + tid * a.ldl : a.logits + (size_t)row * a.ldl;
+    float* dl = staged ? staged + tid * a.ldl : a.dlogits + (size_t)row * a.ldl;    // staged: the gradient replaces the row in LDS
     if (y >= 0 && y < a.n_cls) {
       float mx = -INFINITY;
       for (int c = 0; c < a.n_cls; ++c) mx = fmaxf(mx, lg[c]);
@@ -147,6 +166,13 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(LossArgs a0) {
     } else {
       for (int c = 0; c < a.n_cls; ++c) dl[c] = 0.f;
     }
+    for (int c = a.n_cls; staged && c < a.ldl; ++c) dl[c] = 0.f;     // padding columns of a staged row (none in the model)
+  }
+  if (staged) {                                       // the block's gradient rows leave as one coalesced run
+    __syncthreads();
+    const int row0 = blockIdx.x * 256, total = min(256, rows - row0) * a.ldl;
+    float* dst = a.dlogits + (size_t)row0 * a.ldl;
+    for (int i = tid; i < total; i += 256) dst[i] = staged[i];
   }
   const int gw = blockIdx.x * 4 + (tid >> 6), nw = gridDim.x * 4;
   if (a.dpred_len)

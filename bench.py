@@ -38,22 +38,37 @@ def build_vae(arch="trans4x-256", batch=500, chunks=5):
     return vae
 
 
-def time_gemm(M, N, K, dtype_name, iters=20):
+def time_launches(fn, iters, warm_seconds=0.25):
+    """Average duration (s) of `fn`'s launch at the clock a busy GPU runs at.  An MI355X that has idled (allocation, a host
+    pause) climbs to its working clock over roughly the first 50 ms of load: the same fp32 GEMM launch goes 360 -> 290 us
+    over that stretch (tools/debug/warm_probe.py).  The train step keeps the GPU busy for whole seconds, so the roofline
+    launch is timed the same way: first ~warm_seconds of back-to-back launches, then `iters` timed ones with HIP events on
+    the launch stream (torch's current stream)."""
+    import time
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    while time.time() - t0 < warm_seconds:
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def time_gemm(M, N, K, dtype_name, iters=50):
     """Average duration (s) of the dominant kernel on one representative launch shape."""
     from transvae_amd import ops
     x = torch.randn(M, K, device="cuda")
     w = torch.nn.Parameter(torch.randn(N, K, device="cuda") * 0.05, requires_grad=False)   # a weight, as in the model
     b = torch.zeros(N, device="cuda")
     out = ops.rows_buffer(M, N, "cuda")              # the padded-row buffer the model itself allocates
-    for _ in range(3):
-        ops.linear_fwd(x, w, b, relu=True, out=out)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()                     # events on torch's current stream == the launch stream
-    for _ in range(iters):
-        ops.linear_fwd(x, w, b, relu=True, out=out)
-    e1.record()
-    e1.synchronize()
-    return e0.elapsed_time(e1) * 1e-3 / iters
+    return time_launches(lambda: ops.linear_fwd(x, w, b, relu=True, out=out), iters)
 
 
 def roofline_of(mode, M, N, K):
@@ -104,15 +119,7 @@ def decode_attn_launch(n, n_keys=63, d=256, h=4, T=126):
 def roofline_decode_of(n):
     "roofline object of decode_attn_kernel (HBM-bound), timed live with events on the launch stream"
     fn, nbytes = decode_attn_launch(n)
-    for _ in range(3):
-        fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(20):
-        fn()
-    e1.record()
-    e1.synchronize()
-    t = e0.elapsed_time(e1) * 1e-3 / 20
+    t = time_launches(fn, 20)
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "r2_decode_attn_pmc.json")
     if os.path.exists(pmc):
@@ -229,7 +236,7 @@ def main():
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-extra-modes", action="store_true", help="skip the secondary timings in the other GEMM arithmetics")
     ap.add_argument("--roofline-only", action="store_true",
-                    help="run nothing but the launches of the roofline kernel (3 warm-up + 20 timed) and print its roofline "
+                    help="run nothing but the launches of the roofline kernel (warmed by time, then 50 timed) and print its roofline "
                          "object: under rocprofv3 --kernel-trace --stats the profile then holds exactly these launches")
     args = ap.parse_args()
     if args.gpus < 1:

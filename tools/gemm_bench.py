@@ -1,13 +1,18 @@
 #!/usr/bin/env python3
 """Micro-benchmark of tvae_gemm on the launch shapes of the trans4x-256 train step (HIP events)."""
-import sys, os
+import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from transvae_amd import ops, _lib
 
-def bench(name, fn, flops, iters=10):
-    for _ in range(2):
-        fn()
+def bench(name, fn, flops, iters=20):
+    # an idle MI355X takes ~50 ms of load to reach its working clock: warm up by time, not by launch count
+    fn(); torch.cuda.synchronize()
+    t0 = time.time()
+    while time.time() - t0 < 0.15:
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):

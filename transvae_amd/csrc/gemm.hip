@@ -101,6 +101,29 @@ __device__ inline void stage_load(float4 (&st)[BK / 8], const float* __restrict_
   }
 }
 
+// ---- the same for k-steps that lie wholly inside the operand: no range tests, no per-load address arithmetic -------------
+// Every vector instruction in the k-loop is time the matrix cores stand still (measured, tools/debug/mfma_loop.hip: a bare
+// LDS-fed loop of this shape runs 148 TFLOP/s, 131 with ~60 VALU instructions added per k-step).  So the byte offset of each
+// float4 of a thread is computed ONCE per tile (rows beyond the operand are clamped to its last row: they only ever reach
+// C rows / columns that are not stored, and a_rowsum entries that are not written), the k position advances in a UNIFORM
+// base pointer (scalar registers), and the loads are `base + fixed 32-bit offset`.
+template <int BK, bool KM>
+__device__ inline void stage_offsets(unsigned (&off)[BK / 8], int ld, int row0, int nrows, int tid) {
+#pragma unroll
+  for (int j = 0; j < BK / 8; ++j) {
+    int row, k;
+    stage_pos<BK, KM>(tid + 256 * j, row, k);
+    const int gr = min(row0 + row, KM ? nrows - 4 : nrows - 1);      // KM: a float4 spans rows gr .. gr + 3 (nrows % 4 == 0)
+    off[j] = 4u * (KM ? (unsigned)k * (unsigned)ld + (unsigned)gr : (unsigned)gr * (unsigned)ld + (unsigned)k);
+  }
+}
+template <int BK>
+__device__ inline void stage_load_fast(float4 (&st)[BK / 8], const float* __restrict__ base, const unsigned (&off)[BK / 8]) {
+#pragma unroll
+  for (int j = 0; j < BK / 8; ++j)
+    st[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + off[j]);
+}
+
 template <int BK, bool KM, bool DROP>
 __device__ inline void stage_fix(float4 (&st)[BK / 8], int row0, int nrows, int k0, int kend, int tid,
                                  const DropCfg& dc, int dropM, int dropK) {
@@ -155,9 +178,10 @@ __device__ inline void stage_store_bf16(const float4 (&st)[BK / 8], unsigned sho
   }
 }
 
-template <int BK, bool A_KM, bool B_KM, bool ALIGNED, bool BF16, bool DROP>
+template <int BK, bool A_KM, bool B_KM, bool ALIGNED, bool BF16, bool DROP, bool FAST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BK == 16 ? 4 : 2)))
 void gemm_kernel(GemmArgs g) {
+  static_assert(!FAST || (ALIGNED && !DROP), "fast staging: aligned operands, no A-side dropout mask");
   constexpr int TILE_FLOATS = Tile<BK>::FLOATS, LDS_KC = Tile<BK>::KC, LDS_BF = Tile<BK>::BF;
   constexpr int NJ = Tile<BK>::NJ, HK = Tile<BK>::HK;
   __shared__ __attribute__((aligned(16))) float lds[2 * 2 * TILE_FLOATS];
@@ -171,6 +195,10 @@ void gemm_kernel(GemmArgs g) {
   const int kbeg = blockIdx.z * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
   const int nkt = (kend - kbeg + BK - 1) / BK;
+  // FAST: the k-steps that lie wholly inside [kbeg, kend) are staged without range tests or per-load address arithmetic;
+  // a last partial step (the token count of a weight gradient is not a multiple of BK) goes through the checked path once,
+  // after the loop
+  const int nloop = FAST ? (kend - kbeg) / BK : nkt;
 
   DropCfg dc = drop_cfg(DROP ? g.rng : nullptr, g.site, g.p);
 
@@ -193,30 +221,39 @@ void gemm_kernel(GemmArgs g) {
   auto tileA = [&](int buf) { return lds + (buf * 2 + 0) * TILE_FLOATS; };
   auto tileB = [&](int buf) { return lds + (buf * 2 + 1) * TILE_FLOATS; };
 
-  if (nkt > 0) {
-    stage_load<BK, A_KM, ALIGNED>(sa, g.A, g.lda, m0, g.M, kbeg, kend, tid);
-    stage_load<BK, B_KM, ALIGNED>(sb, g.B, g.ldb, n0, g.N, kbeg, kend, tid);
-    stage_fix<BK, A_KM, DROP>(sa, m0, g.M, kbeg, kend, tid, dc, g.M, g.K);
-    stage_fix<BK, B_KM, false>(sb, n0, g.N, kbeg, kend, tid, nodrop, 0, 0);
+  unsigned offA[FAST ? NJ : 1], offB[FAST ? NJ : 1];
+  if constexpr (FAST) {
+    stage_offsets<BK, A_KM>(offA, g.lda, m0, g.M, tid);
+    stage_offsets<BK, B_KM>(offB, g.ldb, n0, g.N, tid);
+  }
+  // loads of the k-step that starts at k0 (only issued; see stage_load) / what must happen to the registers before the LDS store
+  auto load_step = [&](int k0, bool checked) {
+    if constexpr (FAST) {
+      if (!checked) {
+        stage_load_fast<BK>(sa, g.A + (A_KM ? (size_t)k0 * g.lda : (size_t)k0), offA);
+        stage_load_fast<BK>(sb, g.B + (B_KM ? (size_t)k0 * g.ldb : (size_t)k0), offB);
+        return;
+      }
+    }
+    stage_load<BK, A_KM, ALIGNED>(sa, g.A, g.lda, m0, g.M, k0, kend, tid);
+    stage_load<BK, B_KM, ALIGNED>(sb, g.B, g.ldb, n0, g.N, k0, kend, tid);
+  };
+  auto fix_step = [&](int k0, bool checked) {
+    if (FAST && !checked) return;
+    stage_fix<BK, A_KM, DROP>(sa, m0, g.M, k0, kend, tid, dc, g.M, g.K);
+    stage_fix<BK, B_KM, false>(sb, n0, g.N, k0, kend, tid, nodrop, 0, 0);
+  };
+  auto store_step = [&](int buf) {
     if (do_rowsum) add_rowsum();
     if (BF16) {
-      stage_store_bf16<BK, A_KM>(sa, reinterpret_cast<unsigned short*>(tileA(0)), tid);
-      stage_store_bf16<BK, B_KM>(sb, reinterpret_cast<unsigned short*>(tileB(0)), tid);
+      stage_store_bf16<BK, A_KM>(sa, reinterpret_cast<unsigned short*>(tileA(buf)), tid);
+      stage_store_bf16<BK, B_KM>(sb, reinterpret_cast<unsigned short*>(tileB(buf)), tid);
     } else {
-      stage_store_f32<BK, A_KM>(sa, tileA(0), tid);
-      stage_store_f32<BK, B_KM>(sb, tileB(0), tid);
+      stage_store_f32<BK, A_KM>(sa, tileA(buf), tid);
+      stage_store_f32<BK, B_KM>(sb, tileB(buf), tid);
     }
-  }
-  __syncthreads();
-
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int buf = kt & 1;
-    const bool more = (kt + 1 < nkt);
-    if (more) {
-      int k0 = kbeg + (kt + 1) * BK;
-      stage_load<BK, A_KM, ALIGNED>(sa, g.A, g.lda, m0, g.M, k0, kend, tid);
-      stage_load<BK, B_KM, ALIGNED>(sb, g.B, g.ldb, n0, g.N, k0, kend, tid);
-    }
+  };
+  auto compute = [&](int buf) {
     if (!BF16) {
       const float* TA = tileA(buf);
       const float* TB = tileB(buf);
@@ -287,19 +324,36 @@ void gemm_kernel(GemmArgs g) {
           for (int j = 0; j < 2; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], b[j][ks], acc[i][j], 0, 0, 0);
     }
+  };
+
+  if (nkt > 0) {
+    const bool checked = nloop == 0;           // the only step is a partial one
+    load_step(kbeg, checked);
+    fix_step(kbeg, checked);
+    store_step(0);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nloop; ++kt) {
+    const int buf = kt & 1;
+    const bool more = (kt + 1 < nloop);
+    if (more) load_step(kbeg + (kt + 1) * BK, false);
+    compute(buf);
     if (more) {
-      const int k0 = kbeg + (kt + 1) * BK;
-      stage_fix<BK, A_KM, DROP>(sa, m0, g.M, k0, kend, tid, dc, g.M, g.K);
-      stage_fix<BK, B_KM, false>(sb, n0, g.N, k0, kend, tid, nodrop, 0, 0);
-      if (do_rowsum) add_rowsum();     // after the MFMAs: the loads have landed by now
-      if (BF16) {
-        stage_store_bf16<BK, A_KM>(sa, reinterpret_cast<unsigned short*>(tileA(buf ^ 1)), tid);
-        stage_store_bf16<BK, B_KM>(sb, reinterpret_cast<unsigned short*>(tileB(buf ^ 1)), tid);
-      } else {
-        stage_store_f32<BK, A_KM>(sa, tileA(buf ^ 1), tid);
-        stage_store_f32<BK, B_KM>(sb, tileB(buf ^ 1), tid);
-      }
+      fix_step(kbeg + (kt + 1) * BK, false);   // after the MFMAs: the loads have landed by now
+      store_step(buf ^ 1);
     }
+    __syncthreads();
+  }
+  if (FAST && nkt > nloop) {                   // the partial last k-step, range-checked, not overlapped with anything
+    const int buf = nloop & 1;
+    if (nloop > 0) {
+      load_step(kbeg + nloop * BK, true);
+      fix_step(kbeg + nloop * BK, true);
+      store_step(buf);
+      __syncthreads();
+    }
+    compute(buf);
     __syncthreads();
   }
 
@@ -320,8 +374,14 @@ void gemm_kernel(GemmArgs g) {
 
 template <int BK, bool A_KM, bool B_KM, bool ALIGNED, bool BF16>
 void launch2(const GemmArgs& g, dim3 grid, hipStream_t s, bool drop) {
-  if (drop) hipLaunchKernelGGL((gemm_kernel<BK, A_KM, B_KM, ALIGNED, BF16, true>), grid, dim3(256), 0, s, g);
-  else hipLaunchKernelGGL((gemm_kernel<BK, A_KM, B_KM, ALIGNED, BF16, false>), grid, dim3(256), 0, s, g);
+  if (drop) {
+    hipLaunchKernelGGL((gemm_kernel<BK, A_KM, B_KM, ALIGNED, BF16, true, false>), grid, dim3(256), 0, s, g);
+  } else if constexpr (ALIGNED) {
+    if (g.flags & FLAG_FAST_STAGE) hipLaunchKernelGGL((gemm_kernel<BK, A_KM, B_KM, true, BF16, false, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_kernel<BK, A_KM, B_KM, true, BF16, false, false>), grid, dim3(256), 0, s, g);
+  } else {
+    hipLaunchKernelGGL((gemm_kernel<BK, A_KM, B_KM, ALIGNED, BF16, false, false>), grid, dim3(256), 0, s, g);
+  }
 }
 template <int BK, bool A_KM, bool B_KM>
 void launch1(const GemmArgs& g, dim3 grid, hipStream_t s, bool aligned, bool bf16, bool drop) {
@@ -405,6 +465,12 @@ extern "C" int tvae_gemm(const float* A, int lda, const float* B, int ldb, float
       (!bias || aligned16(bias)) && (!residual || (ldr % 4 == 0 && aligned16(residual))))
     g.flags |= FLAG_VEC_EPILOGUE;
   TVAE_CHECK(!a_rowsum || a_km, TVAE_E_SHAPE, "tvae_gemm: a_rowsum needs a k-major A (wgrad form)");
+  {
+    // fast staging needs every byte offset inside an operand below 4 GiB (32-bit per-thread offsets) and, for the clamped
+    // rows, at least one whole row group to clamp to
+    const double extA = 4.0 * (a_km ? (double)32 * lda + M : (double)M * lda + 32), extB = 4.0 * (b_km ? (double)32 * ldb + N : (double)N * ldb + 32);
+    if (aligned && extA < 4.0e9 && extB < 4.0e9 && M >= 4 && N >= 4) g.flags |= FLAG_FAST_STAGE;
+  }
   const bool bf16 = dtype == TVAE_BF16;
   const bool drop = (flags & TVAE_GEMM_A_DROPMASK) && rng && p_drop > 0.f;
   // split-bf16 kernel: aligned operands only; a k-major A with the A-side dropout mask stays on the fp32 kernel

@@ -6,6 +6,7 @@ namespace {
 
 constexpr int BM = 128, BN = 128;
 constexpr int FLAG_VEC_EPILOGUE = 1 << 20;   // internal: float4 epilogue through LDS (set by the host wrapper)
+constexpr int FLAG_FAST_STAGE = 1 << 21;     // internal: per-tile 32-bit staging offsets + uniform k base (set by the host wrapper)
 constexpr int EPILOGUE_LDS_FLOATS = 4 * 32 * 68;   // what gemm_epilogue needs of the kernel's LDS
 
 struct GemmArgs {

@@ -88,7 +88,7 @@ def roofline_of(mode, M, N, K):
             if rec.get("shape") == [M, N, K]:
                 traffic = rec["traffic_bytes_per_launch"]
                 break
-    kern = {"fp32": "gemm_kernel (v_mfma_f32_32x32x2_f32)", "bf16": "gemm_kernel (v_mfma_f32_32x32x16_bf16)",
+    kern = {"fp32": "gemm_kernel (v_mfma_f32_32x32x2_f32)", "bf16": "gemm_dma_kernel (v_mfma_f32_32x32x16_bf16; fp32 activations and bf16 weights streamed to LDS by LDS-DMA)",
             "f32x3": "gemm3_kernel (6 x v_mfma_f32_32x32x16_bf16 per fp32 product block; peak = bf16 peak / 6)"}[mode]
     return {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[mode], "unit": "TFLOP/s",
             "frac": ach / PEAK_TFLOPS[mode], "traffic": traffic,
@@ -235,6 +235,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-extra-modes", action="store_true", help="skip the secondary timings in the other GEMM arithmetics")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the roofline launches (profiles of the train step alone)")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run nothing but the launches of the roofline kernel (warmed by time, then 50 timed) and print its roofline "
                          "object: under rocprofv3 --kernel-trace --stats the profile then holds exactly these launches")
@@ -426,11 +427,12 @@ def main():
         def roofline(mode):
             return roofline_of(mode, M, N, K)
 
-        out["roofline"] = roofline(args.dtype)
-        if not args.no_decode:
-            out["roofline_decode"] = roofline_decode_of(args.decode_n)
-        if not args.no_extra_modes and args.dtype != "f32x3":
-            out["roofline_f32x3"] = roofline("f32x3")
+        if not args.no_roofline:
+            out["roofline"] = roofline(args.dtype)
+            if not args.no_decode:
+                out["roofline_decode"] = roofline_decode_of(args.decode_n)
+            if not args.no_extra_modes and args.dtype != "f32x3":
+                out["roofline_f32x3"] = roofline("f32x3")
         ops.set_compute_dtype(args.dtype)
         if not args.no_cpu_baseline and world == 1:
             threads = min(16, os.cpu_count() or 1)

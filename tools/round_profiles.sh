@@ -11,9 +11,15 @@ for DT in fp32 f32x3 bf16; do
   bash tools/prof_train.sh $DT ${TAG}_train_$DT > gpurun_out/${TAG}_train_$DT.digest 2>&1 || { echo "prof_train $DT failed"; tail -5 gpurun_out/${TAG}_train_$DT.digest; exit 1; }
   echo "== train $DT"; head -8 gpurun_out/${TAG}_train_$DT.digest
 done
+for DT in fp32 f32x3 bf16; do
+  ( cd /tmp && timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_${TAG}_roofline_$DT" -- python3 "$R/bench.py" --roofline-only --dtype $DT > "$R/gpurun_out/${TAG}_roofline_only_${DT}_line.json" 2> "$R/gpurun_out/${TAG}_roofline_only_$DT.err" ) || { echo "roofline-only $DT failed"; tail -5 gpurun_out/${TAG}_roofline_only_$DT.err; exit 1; }
+  echo "== roofline-only $DT"; cat gpurun_out/${TAG}_roofline_only_${DT}_line.json
+done
 ( cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_${TAG}_decode" -- python3 "$R/tools/decode_bench.py" 65536 > "$R/gpurun_out/${TAG}_decode_result.txt" 2>&1 ) || { echo "decode profile failed"; tail -5 gpurun_out/${TAG}_decode_result.txt; exit 1; }
 echo "== decode"; grep "n=" gpurun_out/${TAG}_decode_result.txt
-bash tools/pmc_traffic.sh > gpurun_out/${TAG}_pmc.log 2>&1 || { echo "pmc failed"; tail -5 gpurun_out/${TAG}_pmc.log; exit 1; }
+PMC_TAG=${TAG} bash tools/pmc_traffic.sh > gpurun_out/${TAG}_pmc.log 2>&1 || { echo "pmc failed"; tail -5 gpurun_out/${TAG}_pmc.log; exit 1; }
 echo "== pmc ok"
+bash tools/pmc_decode.sh ${TAG} > gpurun_out/${TAG}_pmc_decode.log 2>&1 || { echo "pmc decode failed"; tail -5 gpurun_out/${TAG}_pmc_decode.log; exit 1; }
+echo "== pmc decode ok"
 timeout -k 10 400 python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err || { echo "bench failed"; tail -5 gpurun_out/${TAG}_bench_default.err; exit 1; }
 echo "== bench"; cut -c1-330 gpurun_out/${TAG}_bench_default.json

@@ -84,6 +84,45 @@ int tvae_gemm(const float* A, int lda, const float* B, int ldb, float* C, int ld
               float* a_rowsum, int dtype, void* stream);
 
 /*
+ * `batch` independent products of one shape in one launch: C_i = epilogue(op(A_i) op(B_i)), i = 0 .. batch-1, the
+ * matrices of consecutive entries strideA / strideB / strideC (/ strideR) elements apart; flags as tvae_gemm without
+ * split-K, dropout or pre-converted operands; exact fp32.  Replaces torch.bmm(attn_weights, mem) of RNNAttnEncoder
+ * (transvae/rnn_models.py:247) and the two products of its backward.
+ */
+int tvae_gemm_batched(const float* A, int lda, long strideA, const float* B, int ldb, long strideB,
+                      float* C, int ldc, long strideC, int M, int N, int K, int batch,
+                      const float* bias, const float* residual, int ldr, long strideR,
+                      float alpha, int flags, void* stream);
+
+/*
+ * The recurrence of one torch.nn.GRU layer (transvae/rnn_models.py:225/241, 284/301, 320/333, 362/378), gate order
+ * r, z, n as in torch:   gh = h_{t-1} W_hh^T + b_hh,  r = sigmoid(gi_r + gh_r),  z = sigmoid(gi_z + gh_z),
+ * n = tanh(gi_n + r * gh_n),  h_t = (1 - z) n + z h_{t-1}.   gi = x W_ih^T + b_ih for ALL time steps is one tvae_gemm
+ * made by the caller.  Buffers are [B, T, width] (time_major 0: row b * T + t) or [T, B, width] (time_major 1).
+ *   fwd: gi (.., 3H), w_hh (3H, H), b_hh (3H), h0 (B, H) or NULL = zeros -> hseq (.., H); gates (.., 4H) receives
+ *        r, z, n, gh_n for the backward pass (NULL: inference).  T launches, one per time step.
+ *   bwd: dhseq (.., H) gradient arriving at every h_t and/or dh_last (B, H) at the final state (either may be NULL);
+ *        w_hh_t = W_hh^T (H, 3H) -> dgi (.., 3H) gradient of gi, dgh (.., 3H) gradient of gh; carry (B, H) is workspace.
+ *        The caller finishes with plain GEMMs: dx = dgi W_ih, dW_ih = dgi^T x, db_ih = colsum dgi,
+ *        dW_hh = dgh[:, 1:]^T hseq[:, :-1] (+ dgh[:, 0]^T h0), db_hh = colsum dgh.  The gradient of h0 is not produced
+ *        (the reference always starts from zeros, rnn_models.py:262-263).
+ * H must be a multiple of 64.
+ */
+int tvae_gru_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h0, float* hseq, float* gates,
+                 int T, int B, int H, int time_major, void* stream);
+int tvae_gru_bwd(const float* dhseq, const float* dh_last, const float* hseq, const float* gates, const float* h0,
+                 const float* w_hh_t, float* dgi, float* dgh, float* carry, int T, int B, int H, int time_major,
+                 void* stream);
+
+/*
+ * Row softmax y = softmax(x) over n columns and its backward dx = y * (dy - sum(y dy)): the attention weights of
+ * RNNAttnEncoder, F.softmax(self.attn(cat(x, mem)), dim=2) (transvae/rnn_models.py:246).
+ */
+int tvae_softmax_rows_fwd(const float* x, int ldx, float* y, int ldy, int rows, int n, void* stream);
+int tvae_softmax_rows_bwd(const float* y, int ldy, const float* dy, int lddy, float* dx, int lddx, int rows, int n,
+                          void* stream);
+
+/*
  * Three-way bf16 split of an fp32 matrix w (rows x cols, row stride ldw) for the F32X3 arithmetic:
  * w = hi + mid + lo exactly to 2^-26, each a bf16.  out_n (rows, 3*cols): row r holds, for every group
  * of 8 consecutive columns, the 8 hi, the 8 mid and the 8 lo values back to back (cols % 8 == 0);
@@ -215,6 +254,8 @@ int tvae_reparam_bwd(const float* dz, const float* logvar, const float* eps, flo
  *   dlogits (B*126, ldl), dpred_len, dmu, dlogvar, dpred_prop: gradients of `total`
  *   scratch: >= 8*n_groups floats of device workspace (zeroed by the call)
  * KLD NaN guard (loss.py:36-37): if the KLD term is NaN it contributes 0 and no gradient.
+ * pred_len NULL with n_len 0 (and dpred_len NULL): no length head -- vae_loss of the RNN models (loss.py:8-21),
+ * bce_mask is reported as 0.
  */
 int tvae_loss_fwd_bwd(const int64_t* tokens, const float* logits, int ldl, const float* weights,
                       const float* pred_len, const float* mu, const float* logvar,

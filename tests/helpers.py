@@ -162,3 +162,75 @@ def gate_safe_rows(P64, toks, eps, thresholds=None, piece=96):
     unsafe["ffn (7 blocks)"] = int(ffn_bad.sum())
     safe &= ~ffn_bad
     return safe, unsafe
+
+
+# ---- RNN / RNNAttn models ---------------------------------------------------------------------------------------------
+RNN_CONFIGS = {      # tools/make_goldens_rnn.py CONFIGS
+    "rnnattn256": dict(cls="RNNAttn", vocab="zinc", kw=dict(N=3, d_model=256, d_latent=128)),
+    "rnn128_pp": dict(cls="RNN", vocab="pubchem", kw=dict(N=3, d_model=128, d_latent=128, property_predictor=True)),
+    "rnnattn128_notf": dict(cls="RNNAttn", vocab="zinc", kw=dict(N=2, d_model=128, d_latent=128, tf=False)),
+}
+
+
+def rnn_state_shapes(cls, d_model, N=3, d_latent=128, tf=True, property_predictor=False, vocab=26, d_pp=256, depth_pp=2):
+    """Key -> shape table of the reference's RNN / RNNAttn state_dict (transvae/rnn_models.py:81-95, 149-162, 225-231,
+    281-285, 320-323, 362-365), from first principles so that the oracle does not need the product's modules."""
+    S = {}
+
+    def lin(k, o, i):
+        S[k + ".weight"] = (o, i)
+        S[k + ".bias"] = (o,)
+
+    def gru(k, inp):
+        for l in range(N):
+            S["%s.weight_ih_l%d" % (k, l)] = (3 * d_model, inp if l == 0 else d_model)
+            S["%s.weight_hh_l%d" % (k, l)] = (3 * d_model, d_model)
+            S["%s.bias_ih_l%d" % (k, l)] = (3 * d_model,)
+            S["%s.bias_hh_l%d" % (k, l)] = (3 * d_model,)
+
+    gru("encoder.gru", d_model)
+    if cls == "RNNAttn":
+        lin("encoder.attn", 127, 2 * d_model)
+        c = d_model
+        for i, ksz in enumerate((9, 8, 8)):
+            o = 64 if i == 2 else (c - 64) // 2 + 64
+            S["encoder.conv_bottleneck.conv_layers.%d.0.weight" % i] = (o, c, ksz)
+            S["encoder.conv_bottleneck.conv_layers.%d.0.bias" % i] = (o,)
+            c = o
+        lin("encoder.z_means", d_latent, 576)
+        lin("encoder.z_var", d_latent, 576)
+    else:
+        lin("encoder.z_means", d_latent, d_model)
+        lin("encoder.z_var", d_latent, d_model)
+    S["encoder.norm.a_2"] = (d_model,)
+    S["encoder.norm.b_2"] = (d_model,)
+    if cls == "RNNAttn":
+        lin("decoder.linear", 576, d_latent)
+        c = 64
+        for i in range(3):
+            o = d_model if i == 2 else (d_model - c) // 4 + c
+            S["decoder.deconv_bottleneck.deconv_layers.%d.0.weight" % i] = (c, o, 11)
+            S["decoder.deconv_bottleneck.deconv_layers.%d.0.bias" % i] = (o,)
+            c = o
+    gru("decoder.gru", 2 * d_model if tf else d_model)
+    if cls == "RNN":
+        lin("decoder.unbottleneck", d_model, d_latent)
+    S["decoder.norm.a_2"] = (d_model,)
+    S["decoder.norm.b_2"] = (d_model,)
+    S["src_embed.lut.weight"] = (vocab, d_model)
+    S["tgt_embed.lut.weight"] = (vocab, d_model)
+    lin("generator.proj", vocab - 1, d_model)
+    if property_predictor:
+        for i in range(depth_pp):
+            lin("property_predictor.prediction_layers.%d" % i, 1 if i == depth_pp - 1 else d_pp, d_latent if i == 0 else d_pp)
+    return S
+
+
+def rnn_oracle_params(cfg_name, dtype=torch.float32, seed=0, requires_grad=False):
+    cfg = RNN_CONFIGS[cfg_name]
+    shapes = rnn_state_shapes(cfg["cls"], **cfg["kw"])
+    P = {k: torch.from_numpy(synth.synth_tensor(k, s, seed)).to(dtype) for k, s in shapes.items()}
+    if requires_grad:
+        for v in P.values():
+            v.requires_grad_(True)
+    return P

@@ -1,0 +1,73 @@
+"""Pins oracle/rnn_oracle.py against golden vectors captured from the real reference's RNN / RNNAttn models
+(tools/make_goldens_rnn.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rnn_oracle as R
+from transvae_amd import synth
+from helpers import RNN_CONFIGS, load, probe_vec, rel_l2, rnn_oracle_params
+
+NAMES = list(RNN_CONFIGS)
+
+
+def _chunk(name, dtype):
+    g = load("rnn_step_" + name)
+    cfg = RNN_CONFIGS[name]
+    P = rnn_oracle_params(name, dtype, requires_grad=True)
+    toks = torch.from_numpy(g["tokens"].astype(np.int64))
+    w = torch.tensor(synth.load_vocab(cfg["vocab"])[2], dtype=torch.float).to(dtype)
+    logits, mu, logvar, prop = R.forward(P, toks, torch.from_numpy(g["eps"]).to(dtype), cfg["kw"].get("tf", True))
+    losses = R.vae_loss(toks, logits, mu, logvar, torch.from_numpy(g["props"]).to(dtype), prop, w, float(g["beta"]))
+    losses[0].backward()
+    return g, P, losses, dict(logits=logits, mu=mu, logvar=logvar, prop=prop)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_rnn_step_f64(name):
+    g, P, losses, aux = _chunk(name, torch.float64)
+    np.testing.assert_allclose(np.array([float(x) for x in losses]), g["loss_f64"], rtol=1e-11, atol=1e-13)
+    keys = [str(k) for k in g["grad_keys"]]
+    assert set(keys) == {k for k in P if not k.startswith("tgt_embed")}      # tgt_embed is never used (rnn_models.py:207)
+    for i, k in enumerate(keys):
+        gr = P[k].grad.numpy().ravel()
+        nrm = g["grad_norm_f64"][i]
+        assert abs(np.linalg.norm(gr) - nrm) <= 1e-9 * nrm + 1e-14, k
+        assert abs(gr @ probe_vec(k, gr.size) - g["grad_dot_f64"][i]) <= 1e-8 * nrm * np.sqrt(gr.size) + 1e-14, k
+    for f in g.files:
+        if f.startswith("grad_full/"):
+            k = f[len("grad_full/"):]
+            assert rel_l2(P[k].grad.numpy()[:6], g[f]) < 1e-9, k
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_rnn_step_f32_matches_reference_f32(name):
+    g, P, losses, aux = _chunk(name, torch.float32)
+    np.testing.assert_allclose(np.array([float(x) for x in losses]), g["loss_f32"], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(aux["mu"].detach().numpy(), g["mu"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(aux["logvar"].detach().numpy(), g["logvar"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(aux["logits"].detach().numpy()[[0, 2, 5]], g["logits_rows"], rtol=1e-4, atol=5e-6)
+    if "pred_prop" in g.files:
+        np.testing.assert_allclose(aux["prop"].detach().numpy(), g["pred_prop"], rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_rnn_greedy_decode_tokens(name):
+    g = load("rnn_decode_" + name)
+    cfg = RNN_CONFIGS[name]
+    P = rnn_oracle_params(name)
+    cd = synth.load_vocab(cfg["vocab"])[0]
+    tf = cfg["kw"].get("tf", True)
+    with torch.no_grad():
+        z = torch.from_numpy(g["z"])
+        ids, gaps = R.greedy_decode(P, z, teacher_force=tf, margins=True)
+        ids_c = R.greedy_decode(P, z[:6], condition_ids=[cd[str(t)] for t in g["cond"]], teacher_force=tf)
+    # a row may only differ after a near-tie (top-2 logit gap at fp32 resolution)
+    want = g["ids"].astype(np.int64)
+    for r in range(want.shape[0]):
+        diff = np.nonzero(ids[r].numpy() != want[r])[0]
+        if diff.size:
+            assert float(gaps[r, diff[0]]) < 1e-4, (name, r, int(diff[0]), float(gaps[r, diff[0]]))
+    assert (ids.numpy() == want).all(axis=1).mean() >= 0.9
+    assert (ids_c.numpy() == g["ids_cond"].astype(np.int64)).all(axis=1).mean() >= 0.8
+    assert (ids_c[:, :2].numpy() == np.array([cd[str(t)] for t in g["cond"]])).all()

@@ -19,11 +19,16 @@ GEMM_B_SPLIT3 = 128
 GEMM_B_BF16 = 256
 LOSS_STATIC_MAX_GROUPS = 1024
 
-_vp, _i, _f, _u, _i64, _d = C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_int64, C.c_double
+_vp, _i, _f, _u, _i64, _d, _l = C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_int64, C.c_double, C.c_long
 
 # name -> argtypes; every function returns int (0 = ok) except the two string getters.
 SIGNATURES = {
     "tvae_gemm": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _f, _i, _vp, _u, _f, _vp, _i, _vp],
+    "tvae_gemm_batched": [_vp, _i, _l, _vp, _i, _l, _vp, _i, _l, _i, _i, _i, _i, _vp, _vp, _i, _l, _f, _i, _vp],
+    "tvae_gru_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "tvae_gru_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "tvae_softmax_rows_fwd": [_vp, _i, _vp, _i, _i, _i, _vp],
+    "tvae_softmax_rows_bwd": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp],
     "tvae_split3": [_vp, _i, _vp, _vp, _i, _i, _vp],
     "tvae_cast_bf16": [_vp, _i, _vp, _vp, _i, _i, _vp],
     "tvae_colsum": [_vp, _i, _vp, _i, _i, _i, _vp, _u, _f, _vp],

@@ -182,6 +182,11 @@ template <int BK, bool A_KM, bool B_KM, bool ALIGNED, bool BF16, bool DROP, bool
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BK == 16 ? 4 : 2)))
 void gemm_kernel(GemmArgs g) {
   static_assert(!FAST || (ALIGNED && !DROP), "fast staging: aligned operands, no A-side dropout mask");
+  if (gridDim.y > 1) {   // tvae_gemm_batched: one matrix product per blockIdx.y
+    const long by = blockIdx.y;
+    g.A += by * g.sA; g.B += by * g.sB; g.C += by * g.sC;
+    if (g.res) g.res += by * g.sR;
+  }
   constexpr int TILE_FLOATS = Tile<BK>::FLOATS, LDS_KC = Tile<BK>::KC, LDS_BF = Tile<BK>::BF;
   constexpr int NJ = Tile<BK>::NJ, HK = Tile<BK>::HK;
   __shared__ __attribute__((aligned(16))) float lds[2 * 2 * TILE_FLOATS];
@@ -432,10 +437,10 @@ bool fp32_dma_enabled() {   // TVAE_GEMM_DMA=1: exact-fp32 NT products take the 
 }
 }  // namespace
 
-extern "C" int tvae_gemm(const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                         int M, int N, int K, const float* bias, const float* residual, int ldr,
-                         float alpha, int flags, const uint32_t* rng, uint32_t site, float p_drop,
-                         float* a_rowsum, int dtype, void* stream) {
+static int gemm_impl(const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                     int M, int N, int K, const float* bias, const float* residual, int ldr,
+                     float alpha, int flags, const uint32_t* rng, uint32_t site, float p_drop,
+                     float* a_rowsum, int dtype, void* stream, int batch, long sA, long sB, long sC, long sR) {
   TVAE_CHECK(A && B && C, TVAE_E_NULL, "tvae_gemm: null operand");
   TVAE_CHECK(M > 0 && N > 0 && K > 0, TVAE_E_SHAPE, "tvae_gemm: M,N,K must be positive (%d,%d,%d)", M, N, K);
   TVAE_CHECK(dtype == TVAE_F32 || dtype == TVAE_BF16 || dtype == TVAE_F32X3, TVAE_E_DTYPE, "tvae_gemm: dtype %d", dtype);
@@ -456,12 +461,14 @@ extern "C" int tvae_gemm(const float* A, int lda, const float* B, int ldb, float
   // contiguous dimension (k for row-major operands, m/n for k-major ones)
   bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && aligned16(A) && aligned16(B) &&
                  (a_km ? (M % 4 == 0) : (K % 4 == 0)) && (b_km ? (N % 4 == 0) : (K % 4 == 0));
+  if (batch > 1 && (sA % 4 || sB % 4)) aligned = false;
   GemmArgs g;
+  g.sA = sA; g.sB = sB; g.sC = sC; g.sR = sR;
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.res = residual;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.M = M; g.N = N; g.K = K;
   g.alpha = alpha; g.flags = flags; g.rng = rng; g.site = site; g.p = p_drop;
   g.a_rowsum = a_rowsum;
-  if (!(flags & TVAE_GEMM_SPLITK) && N % 4 == 0 && ldc % 4 == 0 && aligned16(C) &&
+  if (!(flags & TVAE_GEMM_SPLITK) && N % 4 == 0 && ldc % 4 == 0 && aligned16(C) && (batch == 1 || (sC % 4 == 0 && sR % 4 == 0)) &&
       (!bias || aligned16(bias)) && (!residual || (ldr % 4 == 0 && aligned16(residual))))
     g.flags |= FLAG_VEC_EPILOGUE;
   TVAE_CHECK(!a_rowsum || a_km, TVAE_E_SHAPE, "tvae_gemm: a_rowsum needs a k-major A (wgrad form)");
@@ -483,7 +490,7 @@ extern "C" int tvae_gemm(const float* A, int lda, const float* B, int ldb, float
                    (a_km ? M % 4 == 0 : true),
                TVAE_E_SHAPE, "tvae_gemm: B_SPLIT3 needs K %% 8 == 0, ldb = 3*Kb with Kb %% 8 == 0, aligned operands");
   }
-  const bool x3 = dtype == TVAE_F32X3 && (b_split || (aligned && !(a_km && drop)));
+  const bool x3 = batch == 1 && dtype == TVAE_F32X3 && (b_split || (aligned && !(a_km && drop)));
   int tiles = cdiv(M, BM) * cdiv(N, BN);
   // streamed NT kernel (gemm_dma.hip): bf16 arithmetic against a weight that is bf16 in memory already, or (switch) exact fp32
   const bool b_bf16 = flags & TVAE_GEMM_B_BF16;
@@ -493,7 +500,7 @@ extern "C" int tvae_gemm(const float* A, int lda, const float* B, int ldb, float
     TVAE_CHECK(K % 32 == 0 && lda % 4 == 0 && aligned16(A) && ldb % 8 == 0 && ldb >= K && aligned16(B), TVAE_E_SHAPE,
                "tvae_gemm: B_BF16 needs K %% 32 == 0 and 16-byte aligned rows (K %d lda %d ldb %d)", K, lda, ldb);
   }
-  const bool dma32 = dtype == TVAE_F32 && fp32_dma_enabled() && !a_km && !b_km && !(flags & TVAE_GEMM_SPLITK) && !drop &&
+  const bool dma32 = batch == 1 && dtype == TVAE_F32 && fp32_dma_enabled() && !a_km && !b_km && !(flags & TVAE_GEMM_SPLITK) && !drop &&
                      K % 16 == 0 && aligned;
   if (b_bf16 || dma32) {
     g.k_per_split = K;
@@ -522,9 +529,33 @@ extern "C" int tvae_gemm(const float* A, int lda, const float* B, int ldb, float
     TVAE_LAUNCH_CHECK("tvae_gemm");
     return TVAE_OK;
   }
-  dim3 grid(tiles, 1, splits);
+  dim3 grid(tiles, batch, splits);
   if (BK == 16) launch0<16>(g, grid, s, a_km, b_km, aligned, bf16, drop);
   else launch0<32>(g, grid, s, a_km, b_km, aligned, bf16, drop);
   TVAE_LAUNCH_CHECK("tvae_gemm");
   return TVAE_OK;
+}
+
+extern "C" int tvae_gemm(const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                         int M, int N, int K, const float* bias, const float* residual, int ldr,
+                         float alpha, int flags, const uint32_t* rng, uint32_t site, float p_drop,
+                         float* a_rowsum, int dtype, void* stream) {
+  return gemm_impl(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, alpha, flags, rng, site, p_drop, a_rowsum, dtype,
+                   stream, 1, 0, 0, 0, 0);
+}
+
+// `batch` independent products of one shape in one launch (blockIdx.y): C_i = epilogue(op(A_i) op(B_i)), matrices of
+// consecutive entries strideA / strideB / strideC (/ strideR for the residual or saved activation) elements apart.
+// The exact-fp32 kernel only: no split-K, no dropout, no pre-split or bf16 operands.
+extern "C" int tvae_gemm_batched(const float* A, int lda, long strideA, const float* B, int ldb, long strideB,
+                                 float* C, int ldc, long strideC, int M, int N, int K, int batch,
+                                 const float* bias, const float* residual, int ldr, long strideR,
+                                 float alpha, int flags, void* stream) {
+  TVAE_CHECK(batch >= 1 && batch <= 65535, TVAE_E_SHAPE, "tvae_gemm_batched: batch %d outside 1..65535", batch);
+  TVAE_CHECK(!(flags & (TVAE_GEMM_SPLITK | TVAE_GEMM_A_DROPMASK | TVAE_GEMM_B_SPLIT3 | TVAE_GEMM_B_BF16)), TVAE_E_SHAPE,
+             "tvae_gemm_batched: split-K, dropout and pre-converted operands are not supported");
+  TVAE_CHECK(strideA >= 0 && strideB >= 0 && strideC >= (long)(M - 1) * ldc + N, TVAE_E_SHAPE,
+             "tvae_gemm_batched: output matrices overlap (strideC %ld)", strideC);
+  return gemm_impl(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, alpha, flags, nullptr, 0, 0.f, nullptr, TVAE_F32,
+                   stream, batch, strideA, strideB, strideC, strideR);
 }

@@ -16,6 +16,7 @@ struct GemmArgs {
   const uint32_t* rng; uint32_t site; float p;
   int k_per_split;
   float* a_rowsum;   // A_KMAJOR only: a_rowsum[m] += sum_k A(m,k) (bias gradient fused into wgrad)
+  long sA, sB, sC, sR;   // tvae_gemm_batched: element strides between the matrices of consecutive batch entries (blockIdx.y)
 };
 
 

@@ -1,0 +1,229 @@
+// GRU recurrence of the RNN / RNNAttn models (reference transvae/rnn_models.py:225,241,284,301,320,333,362,378: torch.nn.GRU)
+// and the row softmax of RNNAttnEncoder's attention weights (rnn_models.py:246).
+//
+// A GRU layer is  gi_t = x_t W_ih^T + b_ih  (no recurrence: ONE large GEMM over all time steps, done by the caller with
+// tvae_gemm) followed, per time step, by
+//     gh_t = h_{t-1} W_hh^T + b_hh                      r = sigmoid(gi_r + gh_r)    z = sigmoid(gi_z + gh_z)
+//     n = tanh(gi_n + r * gh_n)                          h_t = (1 - z) * n + z * h_{t-1}
+// The recurrent part is what this file does: one launch per time step that fuses the [B, H] x [H, 3H] product with the gate
+// arithmetic.  Batch rows are independent and the hidden units of one step are independent, so a step is a grid of
+// 16-row x 16-unit tiles; the four waves of a workgroup split K (each lane reads whole 64-byte runs of its operand rows
+// straight into MFMA operand registers -- v_mfma_f32_16x16x4_f32 takes any k order as long as A and B agree), add their
+// partial tiles through LDS, and every thread then finishes one (row, unit).  The backward step is the same product shape
+// against W_hh^T (K = 3H) fused with the gate derivatives; weight gradients are left to two large GEMMs over all steps.
+#include "common.h"
+
+namespace {
+
+struct GruArgs {
+  const float* gi;      // [B, T, 3H]  input projections (+ b_ih), row (b, t) at (b * sb + t * st) * 3H
+  const float* w;       // fwd: W_hh [3H, H]      bwd: W_hh^T [H, 3H]
+  const float* b_hh;    // [3H]
+  const float* h0;      // [B, H] or null (zeros)
+  float* hseq;          // [B, T, H]   h_t
+  float* gates;         // [B, T, 4H]  r, z, n, gh_n + b_hn   (null: inference)
+  const float* dhseq;   // bwd: [B, T, H] gradient arriving at every h_t (null: none)
+  const float* dh_last; // bwd: [B, H] extra gradient of the final state (null: none)
+  float* dgi;           // bwd: [B, T, 3H] gradient of gi  (dr_pre, dz_pre, dn_pre)
+  float* dgh;           // bwd: [B, T, 3H] gradient of gh  (dr_pre, dz_pre, dn_pre * r)
+  float* carry;         // bwd: [B, H] dh_{t+1} * z_{t+1}
+  int T, B, H, sb, st, t;
+};
+
+__device__ inline float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// partial[g][r] of this wave: rows 4 * (lane / 16) + r, unit lane % 16, over the wave's quarter of K.
+// A rows are `lda` floats apart, rows of W `ldw`; NG accumulators use W rows u0 + g * gstride + j.
+template <int NG>
+__device__ inline void tile_product(const float* __restrict__ A, long lda, int rows_valid, const float* __restrict__ W, int ldw,
+                                    int gstride, int K, int wave, int lane, floatx4 (&acc)[NG]) {
+  const int i = lane & 15, kq = lane >> 4;
+  const int kw = K >> 2;                 // this wave's share of K
+  const int kl = kw >> 2;                // floats per lane: a contiguous run
+  const float* ap = A + (long)(i < rows_valid ? i : 0) * lda + wave * kw + kq * kl;
+  const float* wp = W + (long)i * ldw + wave * kw + kq * kl;
+  for (int c = 0; c < kl; c += 4) {
+    const float4 a = *reinterpret_cast<const float4*>(ap + c);
+    float4 b[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) b[g] = *reinterpret_cast<const float4*>(wp + (long)g * gstride * ldw + c);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[g].x, acc[g], 0, 0, 0);
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[g].y, acc[g], 0, 0, 0);
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[g].z, acc[g], 0, 0, 0);
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[g].w, acc[g], 0, 0, 0);
+    }
+  }
+}
+
+// sum over the four waves of accumulator g for thread tid's (row i = tid / 16, unit j = tid % 16)
+template <int NG>
+__device__ inline void reduce_tiles(floatx4 (&acc)[NG], float* red, int wave, int lane, int tid, float (&out)[NG]) {
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[((wave * NG + g) * 4 + r) * 64 + lane] = acc[g][r];
+  __syncthreads();
+  const int i = tid >> 4, j = tid & 15;
+  const int src = 16 * (i >> 2) + j, r = i & 3;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s += red[((w * NG + g) * 4 + r) * 64 + src];
+    out[g] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void gru_fwd_step(GruArgs a) {
+  __shared__ float red[4 * 3 * 4 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b0 = blockIdx.x * 16, u0 = blockIdx.y * 16;
+  const int H = a.H, t = a.t;
+  const long rowstep = (long)a.sb;       // rows between consecutive batch entries at one time step
+  const float* hprev_base = t > 0 ? a.hseq + ((long)b0 * a.sb + (long)(t - 1) * a.st) * H : (a.h0 ? a.h0 + (long)b0 * H : nullptr);
+  const long hprev_ld = t > 0 ? rowstep * H : H;
+  floatx4 acc[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) acc[g] = floatx4{0.f, 0.f, 0.f, 0.f};
+  if (hprev_base) tile_product<3>(hprev_base, hprev_ld, a.B - b0, a.w + (long)u0 * H, H, H, H, wave, lane, acc);
+  float gh[3];
+  reduce_tiles<3>(acc, red, wave, lane, tid, gh);
+  const int i = tid >> 4, j = tid & 15, b = b0 + i, u = u0 + j;
+  if (b >= a.B) return;
+  const long row = (long)b * a.sb + (long)t * a.st;
+  const float* gi = a.gi + row * 3 * H;
+  const float hr = gh[0] + a.b_hh[u], hz = gh[1] + a.b_hh[H + u], hn = gh[2] + a.b_hh[2 * H + u];
+  const float r = sigmoidf_(gi[u] + hr), z = sigmoidf_(gi[H + u] + hz);
+  const float n = tanhf(gi[2 * H + u] + r * hn);
+  const float hp = hprev_base ? hprev_base[(long)i * hprev_ld + u] : 0.f;
+  a.hseq[row * H + u] = (1.f - z) * n + z * hp;
+  if (a.gates) {
+    float* G = a.gates + row * 4 * H;
+    G[u] = r; G[H + u] = z; G[2 * H + u] = n; G[3 * H + u] = hn;
+  }
+}
+
+__global__ __launch_bounds__(256) void gru_bwd_step(GruArgs a) {
+  __shared__ float red[4 * 1 * 4 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b0 = blockIdx.x * 16, u0 = blockIdx.y * 16;
+  const int H = a.H, t = a.t;
+  floatx4 acc[1] = {floatx4{0.f, 0.f, 0.f, 0.f}};
+  const bool last = t == a.T - 1;
+  if (!last) {
+    const float* dgh_next = a.dgh + ((long)b0 * a.sb + (long)(t + 1) * a.st) * 3 * H;
+    tile_product<1>(dgh_next, (long)a.sb * 3 * H, a.B - b0, a.w + (long)u0 * 3 * H, 3 * H, 0, 3 * H, wave, lane, acc);
+  }
+  float back[1];
+  reduce_tiles<1>(acc, red, wave, lane, tid, back);
+  const int i = tid >> 4, j = tid & 15, b = b0 + i, u = u0 + j;
+  if (b >= a.B) return;
+  const long row = (long)b * a.sb + (long)t * a.st;
+  float dh = a.dhseq ? a.dhseq[row * H + u] : 0.f;
+  if (last) dh += a.dh_last ? a.dh_last[(long)b * H + u] : 0.f;
+  else dh += a.carry[(long)b * H + u] + back[0];
+  const float* G = a.gates + row * 4 * H;
+  const float r = G[u], z = G[H + u], n = G[2 * H + u], hn = G[3 * H + u];
+  const float hp = t > 0 ? a.hseq[(row - a.st) * H + u] : (a.h0 ? a.h0[(long)b * H + u] : 0.f);
+  const float dn = dh * (1.f - z), dz = dh * (hp - n);
+  const float dnp = dn * (1.f - n * n);
+  const float drp = dnp * hn * r * (1.f - r), dzp = dz * z * (1.f - z);
+  float* dgi = a.dgi + row * 3 * H;
+  float* dgh = a.dgh + row * 3 * H;
+  dgi[u] = drp; dgi[H + u] = dzp; dgi[2 * H + u] = dnp;
+  dgh[u] = drp; dgh[H + u] = dzp; dgh[2 * H + u] = dnp * r;
+  a.carry[(long)b * H + u] = dh * z;
+}
+
+// one wave per row: y = softmax(x) / dx = y * (dy - sum(y dy))
+__global__ __launch_bounds__(256) void softmax_rows_fwd(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int rows, int n) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (long)row * ldx;
+  float mx = -INFINITY;
+  for (int c = lane; c < n; c += 64) mx = fmaxf(mx, xr[c]);
+  mx = wave_max(mx);
+  float se = 0.f;
+  for (int c = lane; c < n; c += 64) se += expf(xr[c] - mx);
+  se = wave_sum(se);
+  const float inv = 1.f / se;
+  for (int c = lane; c < n; c += 64) y[(long)row * ldy + c] = expf(xr[c] - mx) * inv;
+}
+
+__global__ __launch_bounds__(256) void softmax_rows_bwd(const float* __restrict__ y, int ldy, const float* __restrict__ dy, int lddy,
+                                                        float* __restrict__ dx, int lddx, int rows, int n) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* yr = y + (long)row * ldy;
+  const float* dr = dy + (long)row * lddy;
+  float s = 0.f;
+  for (int c = lane; c < n; c += 64) s += yr[c] * dr[c];
+  s = wave_sum(s);
+  for (int c = lane; c < n; c += 64) dx[(long)row * lddx + c] = yr[c] * (dr[c] - s);
+}
+
+int check_gru(const char* who, int T, int B, int H, int time_major) {
+  TVAE_CHECK(T > 0 && B > 0 && H > 0, TVAE_E_SHAPE, "%s: T, B, H must be positive (%d, %d, %d)", who, T, B, H);
+  TVAE_CHECK(H % 64 == 0, TVAE_E_SHAPE, "%s: hidden size %d must be a multiple of 64", who, H);
+  TVAE_CHECK(time_major == 0 || time_major == 1, TVAE_E_SHAPE, "%s: time_major must be 0 or 1", who);
+  TVAE_CHECK((long)B * T * 4 * H < (1L << 40), TVAE_E_SHAPE, "%s: sequence buffer too large", who);
+  return TVAE_OK;
+}
+
+}  // namespace
+
+extern "C" int tvae_gru_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h0, float* hseq, float* gates,
+                            int T, int B, int H, int time_major, void* stream) {
+  TVAE_CHECK(gi && w_hh && b_hh && hseq, TVAE_E_NULL, "tvae_gru_fwd: null pointer");
+  if (int e = check_gru("tvae_gru_fwd", T, B, H, time_major)) return e;
+  TVAE_CHECK(aligned16(w_hh) && aligned16(hseq) && (!h0 || aligned16(h0)), TVAE_E_SHAPE, "tvae_gru_fwd: operands must be 16-byte aligned");
+  GruArgs a = {};
+  a.gi = gi; a.w = w_hh; a.b_hh = b_hh; a.h0 = h0; a.hseq = hseq; a.gates = gates;
+  a.T = T; a.B = B; a.H = H; a.sb = time_major ? 1 : T; a.st = time_major ? B : 1;
+  const dim3 grid(cdiv(B, 16), H / 16);
+  for (int t = 0; t < T; ++t) {
+    a.t = t;
+    hipLaunchKernelGGL(gru_fwd_step, grid, dim3(256), 0, (hipStream_t)stream, a);
+  }
+  TVAE_LAUNCH_CHECK("tvae_gru_fwd");
+  return TVAE_OK;
+}
+
+extern "C" int tvae_gru_bwd(const float* dhseq, const float* dh_last, const float* hseq, const float* gates, const float* h0,
+                            const float* w_hh_t, float* dgi, float* dgh, float* carry, int T, int B, int H, int time_major,
+                            void* stream) {
+  TVAE_CHECK(hseq && gates && w_hh_t && dgi && dgh && carry, TVAE_E_NULL, "tvae_gru_bwd: null pointer");
+  TVAE_CHECK(dhseq || dh_last, TVAE_E_NULL, "tvae_gru_bwd: neither dhseq nor dh_last given");
+  if (int e = check_gru("tvae_gru_bwd", T, B, H, time_major)) return e;
+  TVAE_CHECK(aligned16(w_hh_t) && aligned16(dgh), TVAE_E_SHAPE, "tvae_gru_bwd: operands must be 16-byte aligned");
+  GruArgs a = {};
+  a.w = w_hh_t; a.h0 = h0; a.hseq = const_cast<float*>(hseq); a.gates = const_cast<float*>(gates);
+  a.dhseq = dhseq; a.dh_last = dh_last; a.dgi = dgi; a.dgh = dgh; a.carry = carry;
+  a.T = T; a.B = B; a.H = H; a.sb = time_major ? 1 : T; a.st = time_major ? B : 1;
+  const dim3 grid(cdiv(B, 16), H / 16);
+  for (int t = T - 1; t >= 0; --t) {
+    a.t = t;
+    hipLaunchKernelGGL(gru_bwd_step, grid, dim3(256), 0, (hipStream_t)stream, a);
+  }
+  TVAE_LAUNCH_CHECK("tvae_gru_bwd");
+  return TVAE_OK;
+}
+
+extern "C" int tvae_softmax_rows_fwd(const float* x, int ldx, float* y, int ldy, int rows, int n, void* stream) {
+  TVAE_CHECK(x && y, TVAE_E_NULL, "tvae_softmax_rows_fwd: null pointer");
+  TVAE_CHECK(rows > 0 && n > 0 && ldx >= n && ldy >= n, TVAE_E_SHAPE, "tvae_softmax_rows_fwd: bad shape (rows %d n %d ldx %d ldy %d)", rows, n, ldx, ldy);
+  hipLaunchKernelGGL(softmax_rows_fwd, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, n);
+  TVAE_LAUNCH_CHECK("tvae_softmax_rows_fwd");
+  return TVAE_OK;
+}
+
+extern "C" int tvae_softmax_rows_bwd(const float* y, int ldy, const float* dy, int lddy, float* dx, int lddx, int rows, int n,
+                                     void* stream) {
+  TVAE_CHECK(y && dy && dx, TVAE_E_NULL, "tvae_softmax_rows_bwd: null pointer");
+  TVAE_CHECK(rows > 0 && n > 0 && ldy >= n && lddy >= n && lddx >= n, TVAE_E_SHAPE, "tvae_softmax_rows_bwd: bad shape");
+  hipLaunchKernelGGL(softmax_rows_bwd, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, y, ldy, dy, lddy, dx, lddx, rows, n);
+  TVAE_LAUNCH_CHECK("tvae_softmax_rows_bwd");
+  return TVAE_OK;
+}

@@ -32,7 +32,7 @@ __device__ inline LossArgs for_group(LossArgs a, int g) {
   const size_t m0 = (size_t)g * Bg;
   a.tokens += m0 * (a.L + 1);
   a.logits += m0 * a.L * a.ldl;
-  a.pred_len += m0 * a.n_len;
+  if (a.pred_len) a.pred_len += m0 * a.n_len;
   a.mu += m0 * a.d_latent;
   a.logvar += m0 * a.d_latent;
   if (a.pred_prop) { a.pred_prop += m0; a.true_prop += m0; }
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(LossArgs a0) {
   // length-prediction CE: one wave per molecule, molecules strided over the grid's waves
   float nl = 0.f;
   const int gw = blockIdx.x * 4 + (tid >> 6), nw = gridDim.x * 4;
-  for (int b = gw; b < a.B; b += nw) {
+  for (int b = gw; a.pred_len && b < a.B; b += nw) {     // no length head (vae_loss of the RNN models): the term is 0
     int cnt = 0;
     if (a.true_len) {
       cnt = (int)a.true_len[b];
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(LossArgs a0) {
     for (int i = tid; i < total; i += 256) dst[i] = staged[i];
   }
   const int gw = blockIdx.x * 4 + (tid >> 6), nw = gridDim.x * 4;
-  if (a.dpred_len)
+  if (a.dpred_len && a.pred_len)
     for (int b = gw; b < a.B; b += nw) {
       int cnt = 0;
       if (a.true_len) {
@@ -382,8 +382,10 @@ static int loss_launch(const int64_t* tokens, const float* logits, int ldl, cons
                        const int64_t* true_len, float beta, int B, int L, int n_cls, int n_len, int d_latent, int pad_idx,
                        int n_groups, float* out5, float* dlogits, float* dpred_len, float* dmu, float* dlogvar,
                        float* dpred_prop, float* sums, hipStream_t s, const char* who) {
-  TVAE_CHECK(tokens && logits && weights && pred_len && mu && logvar && out5 && sums, TVAE_E_NULL, "%s: null pointer", who);
-  TVAE_CHECK(B > 0 && L > 0 && n_cls > 0 && n_cls <= ldl && n_len > 0 && d_latent > 0, TVAE_E_SHAPE,
+  TVAE_CHECK(tokens && logits && weights && mu && logvar && out5 && sums, TVAE_E_NULL, "%s: null pointer", who);
+  // pred_len may be NULL (with n_len 0): the loss without the length-prediction term, vae_loss of the reference (loss.py:8-21)
+  TVAE_CHECK((pred_len != nullptr) == (n_len > 0) && (pred_len || !dpred_len), TVAE_E_SHAPE, "%s: pred_len and n_len %d disagree", who, n_len);
+  TVAE_CHECK(B > 0 && L > 0 && n_cls > 0 && n_cls <= ldl && n_len >= 0 && d_latent > 0, TVAE_E_SHAPE,
              "%s: bad shape B=%d L=%d n_cls=%d ldl=%d", who, B, L, n_cls, ldl);
   TVAE_CHECK(!pred_prop || true_prop, TVAE_E_NULL, "%s: pred_prop without true_prop", who);
   TVAE_CHECK((dmu == nullptr) == (dlogvar == nullptr), TVAE_E_NULL, "%s: dmu/dlogvar must come together", who);

@@ -23,5 +23,9 @@ def trans_vae_loss(x, x_out, mu, logvar, true_len, pred_len, true_prop, pred_pro
 
 
 def vae_loss(x, x_out, mu, logvar, true_prop, pred_prop, weights, beta=1):
-    """RNN-model loss of the reference (transvae/loss.py:8-21): out of scope."""
-    raise NotImplementedError("vae_loss belongs to the RNN models, which this build does not cover")
+    """Weighted token cross-entropy + beta * KL (+ property MSE): the loss of the RNN models, same signature and return
+    order as the reference (transvae/loss.py:8-21): ``(total, BCE, KLD, MSE)``.  The same fused kernel as trans_vae_loss,
+    launched without a length head."""
+    total, bce, _, kld, mse = ops.LossFn.apply(x.long(), x_out, mu, logvar, None, true_prop, pred_prop,
+                                               weights.to(torch.float32), float(beta), weights.shape[0] - 1, None)
+    return total, bce, kld, mse

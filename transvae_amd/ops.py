@@ -846,17 +846,18 @@ def loss_fwd_bwd(tokens, logits, weights, pred_len, mu, logvar, pred_prop, true_
     out5 = torch.empty((n_groups, 5), device=dev, dtype=torch.float32)
     scratch = torch.empty(8 * n_groups, device=dev, dtype=torch.float32)
     g = {}
+    n_len = 0 if pred_len is None else pred_len.shape[1]      # None: vae_loss of the RNN models, no length head
     if want_grads:
         g["logits"] = torch.empty_like(lg)
-        g["pred_len"] = torch.empty_like(pred_len)
+        g["pred_len"] = None if pred_len is None else torch.empty_like(pred_len)
         g["mu"] = torch.empty_like(mu)
         g["logvar"] = torch.empty_like(logvar)
         g["pred_prop"] = torch.empty(B, device=dev, dtype=torch.float32) if pred_prop is not None else None
     pp = None if pred_prop is None else _c(pred_prop).view(-1)
     tp = None if pred_prop is None else _c(true_prop.to(torch.float32)).view(-1)
     tl = None if true_len is None else _c(true_len.long()).view(-1)
-    call("tvae_loss_fwd_bwd", _p(_c(tokens)), _p(lg), lg.stride(0), _p(weights), _p(_c(pred_len)), _p(_c(mu)),
-         _p(_c(logvar)), _p(pp), _p(tp), _p(tl), float(beta), B, L, n_cls, pred_len.shape[1], mu.shape[1], int(pad_idx), int(n_groups),
+    call("tvae_loss_fwd_bwd", _p(_c(tokens)), _p(lg), lg.stride(0), _p(weights), _p(None if pred_len is None else _c(pred_len)), _p(_c(mu)),
+         _p(_c(logvar)), _p(pp), _p(tp), _p(tl), float(beta), B, L, n_cls, n_len, mu.shape[1], int(pad_idx), int(n_groups),
          _p(out5), _p(g.get("logits")), _p(g.get("pred_len")), _p(g.get("mu")), _p(g.get("logvar")),
          _p(g.get("pred_prop")), _p(scratch), _stream())
     return (out5 if n_groups > 1 else out5[0]), g
@@ -882,7 +883,8 @@ class LossFn(torch.autograd.Function):
         dpp = None
         if g["pred_prop"] is not None:
             dpp = (g["pred_prop"] * gt).view(ctx.shapes[1])
-        return (None, (g["logits"] * gt).view(ctx.shapes[0]), g["mu"] * gt, g["logvar"] * gt, g["pred_len"] * gt,
+        dpl = None if g["pred_len"] is None else g["pred_len"] * gt
+        return (None, (g["logits"] * gt).view(ctx.shapes[0]), g["mu"] * gt, g["logvar"] * gt, dpl,
                 None, dpp, None, None, None, None)
 
 
@@ -1001,3 +1003,135 @@ class PosEncFn(torch.autograd.Function):
         r, s, p = _drop_args(ctx.drop)
         call("tvae_residual_dropout", _p(dy2), None, _p(dx2), dy2.shape[0], dy2.shape[1], 0, 0, r, s, p, _stream())
         return dx2.view(dy.shape), None, None
+
+
+# ----------------------------------------------------------------------------- GRU (RNN / RNNAttn models)
+def _dropped(x2, drop):
+    "x2 * keep-mask / (1 - p) as a new tensor (None drop: x2 itself)"
+    if drop is None:
+        return x2
+    out = torch.empty_like(x2)
+    r, s, p = _drop_args(drop)
+    call("tvae_residual_dropout", _p(x2), None, _p(out), x2.shape[0], x2.shape[1], 0, 0, r, s, p, _stream())
+    return out
+
+
+class GRUStackFn(torch.autograd.Function):
+    """torch.nn.GRU(num_layers=N, dropout=p) on a (B, T, I) input from h0 = 0 (reference transvae/rnn_models.py:241, 301,
+    333, 378): returns (output of the top layer (B, T, H), final state of the top layer (B, H)).
+
+    Per layer: the input projections of ALL time steps are one GEMM, the recurrence is tvae_gru_fwd (one fused launch per
+    time step), the inter-layer dropout is a mask regenerated in the backward pass.  Inside, sequences are time-major
+    (T, B, .) with a leading block of B zero rows (h_{-1}): the rows of h_{t-1} then sit exactly B rows before those of
+    h_t, which makes the recurrent weight gradient ONE product dgh^T [0; h_0 .. h_{T-2}] over all steps."""
+
+    @staticmethod
+    def forward(ctx, x, drops, *params):
+        B, T, I = x.shape
+        n_layers = len(params) // 4
+        H = params[1].shape[1]
+        _chk(x, "x")
+        cur = x.transpose(0, 1).contiguous().view(T * B, I)
+        need_grad = any(ctx.needs_input_grad)          # False under torch.no_grad(): nothing is kept for a backward pass
+        saved = []
+        for l in range(n_layers):
+            w_ih, w_hh, b_ih, b_hh = params[4 * l:4 * l + 4]
+            xin = _dropped(cur, drops[l - 1]) if l > 0 else cur
+            gi = linear_fwd(xin, w_ih, b_ih)
+            hbuf = torch.empty(((T + 1) * B, H), device=x.device, dtype=torch.float32)
+            hbuf[:B].zero_()
+            hseq = hbuf[B:]
+            gates = torch.empty((T * B, 4 * H), device=x.device, dtype=torch.float32) if need_grad else None
+            call("tvae_gru_fwd", _p(gi), _p(w_hh), _p(b_hh), None, _p(hseq), _p(gates), T, B, H, 1, _stream())
+            if need_grad:
+                saved += [xin, hbuf, gates]
+            cur = hseq
+        out = cur.view(T, B, H).transpose(0, 1).contiguous()
+        h_last = cur.view(T, B, H)[T - 1].clone()
+        ctx.save_for_backward(*saved)
+        ctx.P, ctx.drops, ctx.dims = params, drops, (B, T, I, H, n_layers)
+        _note_use(*params)
+        return out, h_last
+
+    @staticmethod
+    def backward(ctx, dout, dh_last):
+        B, T, I, H, n_layers = ctx.dims
+        saved, params = ctx.saved_tensors, ctx.P
+        dev = saved[0].device
+        d = None if dout is None else dout.transpose(0, 1).contiguous().view(T * B, H)
+        dl = None if dh_last is None else _c(dh_last)
+        grads = [None] * (4 * n_layers)
+        for l in range(n_layers - 1, -1, -1):
+            w_ih, w_hh, b_ih, b_hh = params[4 * l:4 * l + 4]
+            xin, hbuf, gates = saved[3 * l:3 * l + 3]
+            dgi = torch.empty((T * B, 3 * H), device=dev, dtype=torch.float32)
+            dgh = torch.empty((T * B, 3 * H), device=dev, dtype=torch.float32)
+            carry = torch.empty((B, H), device=dev, dtype=torch.float32)
+            w_hh_t = w_hh.detach().t().contiguous()
+            call("tvae_gru_bwd", _p(d), _p(dl), _p(hbuf[B:]), _p(gates), None, _p(w_hh_t), _p(dgi), _p(dgh), _p(carry),
+                 T, B, H, 1, _stream())
+            dl = None
+            grads[4 * l], grads[4 * l + 2] = linear_wgrad(dgi, xin, W=w_ih, b=b_ih)
+            grads[4 * l + 1], grads[4 * l + 3] = linear_wgrad(dgh, hbuf[:T * B], W=w_hh, b=b_hh)
+            if l > 0 or ctx.needs_input_grad[0]:
+                d = linear_dgrad(dgi, w_ih)
+                if l > 0:
+                    d = _dropped(d, ctx.drops[l - 1])
+        dx = d.view(T, B, I).transpose(0, 1).contiguous() if ctx.needs_input_grad[0] else None
+        return (dx, None) + tuple(grads)
+
+
+class SoftmaxFn(torch.autograd.Function):
+    "softmax over the last dimension (F.softmax(.., dim=2) of RNNAttnEncoder, rnn_models.py:246)"
+
+    @staticmethod
+    def forward(ctx, x):
+        x2 = _c(x).view(-1, x.shape[-1])
+        _chk(x2, "x")
+        y = torch.empty_like(x2)
+        call("tvae_softmax_rows_fwd", _p(x2), x2.stride(0), _p(y), y.stride(0), x2.shape[0], x2.shape[1], _stream())
+        ctx.save_for_backward(y)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy2 = _c(dy).view(y.shape)
+        dx = torch.empty_like(y)
+        call("tvae_softmax_rows_bwd", _p(y), y.stride(0), _p(dy2), dy2.stride(0), _p(dx), dx.stride(0), y.shape[0], y.shape[1],
+             _stream())
+        return dx.view(dy.shape)
+
+
+def gemm_batched(A, lda, sA, Bm, ldb, sB, Cm, ldc, sC, M, N, K, batch, residual=None, ldr=0, sR=0, flags=0):
+    call("tvae_gemm_batched", _p(A), lda, sA, _p(Bm), ldb, sB, _p(Cm), ldc, sC, M, N, K, batch, None, _p(residual), ldr, sR,
+         1.0, flags, _stream())
+
+
+class BmmReluFn(torch.autograd.Function):
+    "relu(torch.bmm(p, v)): p (B, L, S) attention weights, v (B, S, d)  (rnn_models.py:247-248), one launch for all B"
+
+    @staticmethod
+    def forward(ctx, p, v):
+        p, v = _c(p), _c(v)
+        _chk(p, "p")
+        _chk(v, "v")
+        B, L, S = p.shape
+        d = v.shape[2]
+        out = torch.empty((B, L, d), device=p.device, dtype=torch.float32)
+        gemm_batched(p, S, L * S, v, d, S * d, out, d, L * d, L, d, S, B, flags=GEMM_B_KMAJOR | GEMM_RELU)
+        ctx.save_for_backward(p, v, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        p, v, out = ctx.saved_tensors
+        B, L, S = p.shape
+        d = v.shape[2]
+        dpre = relu_mask(_c(dout).view(B * L, d), out.view(B * L, d))
+        dp = torch.empty_like(p)
+        dv = torch.empty_like(v)
+        gemm_batched(dpre, d, L * d, v, d, S * d, dp, S, L * S, L, S, d, B)                       # dpre_b v_b^T
+        gemm_batched(p, S, L * S, dpre, d, L * d, dv, d, S * d, S, d, L, B,
+                     flags=GEMM_A_KMAJOR | GEMM_B_KMAJOR)                                          # p_b^T dpre_b
+        return dp, dv

@@ -469,7 +469,7 @@ import numpy as np  # noqa: E402
 
 from .data import DeviceDataset, DeviceLoader, make_src_mask, make_std_mask, vae_data_gen  # noqa: E402
 from .decode import GreedyDecoder  # noqa: E402
-from .loss import trans_vae_loss  # noqa: E402
+from .loss import trans_vae_loss, vae_loss  # noqa: E402, F401
 from .opt import Adam, NoamOpt  # noqa: E402
 from .tvae_util import KLAnnealer, decode_mols  # noqa: E402
 
@@ -518,7 +518,7 @@ class VAEShell():
                 self.params['CHAR_WEIGHTS'] = torch.as_tensor(self.params['CHAR_WEIGHTS']).detach().clone().float()
             else:
                 self.params['CHAR_WEIGHTS'] = torch.ones(self.vocab_size, dtype=torch.float)
-        self.loss_func = trans_vae_loss
+        self.loss_func = vae_loss          # as the reference (:49); the transformer's train loop calls trans_vae_loss itself
         self.data_gen = vae_data_gen
         self.src_len = 126
         self.tgt_len = 125
@@ -572,14 +572,31 @@ class VAEShell():
         tgt = src[:, :-1]
         return src, tgt, chunk[:, -1], make_src_mask(src, self.pad_idx), make_std_mask(tgt, self.pad_idx)
 
+    def _model_forward(self, src, tgt, src_mask, tgt_mask, eps=None):
+        """(x_out, mu, logvar, pred_len, pred_prop) of either model family: the RNN models have no length head and their
+        loss no length term (reference :217-231: trans_vae_loss vs vae_loss), so pred_len is None there"""
+        if self.model_type == 'transformer':
+            return self.model(src, tgt, src_mask, tgt_mask, eps)
+        x_out, mu, logvar, pred_prop = self.model(src, tgt, src_mask, tgt_mask, eps)
+        return x_out, mu, logvar, None, pred_prop
+
+    def _encode(self, src, src_mask):
+        "(mem, mu, logvar) of either model family (reference :486-489, :593-596)"
+        if self.model_type == 'transformer':
+            return self.model.encode(src, src_mask)[:3]
+        return self.model.encode(src)
+
     def _forward_backward(self, data, beta, eps, n_groups, table, row0):
         src, tgt, true_prop, src_mask, tgt_mask = self._chunk_inputs(data)
-        x_out, mu, logvar, pred_len, pred_prop = self.model(src, tgt, src_mask, tgt_mask, eps)
+        x_out, mu, logvar, pred_len, pred_prop = self._model_forward(src, tgt, src_mask, tgt_mask, eps)
         out5, g = ops.loss_fwd_bwd(src, x_out, self.params['CHAR_WEIGHTS'], pred_len, mu, logvar, pred_prop,
                                    true_prop, beta, self.pad_idx, n_groups=n_groups)
         table[row0:row0 + n_groups].copy_(out5.view(n_groups, 5))
-        outs = [x_out, mu, logvar, pred_len]
-        grads = [g['logits'].view(x_out.shape), g['mu'], g['logvar'], g['pred_len']]
+        outs = [x_out, mu, logvar]
+        grads = [g['logits'].view(x_out.shape), g['mu'], g['logvar']]
+        if pred_len is not None:
+            outs.append(pred_len)
+            grads.append(g['pred_len'])
         if pred_prop is not None:
             outs.append(pred_prop)
             grads.append(g['pred_prop'].view(pred_prop.shape))
@@ -643,7 +660,7 @@ class VAEShell():
         if data.shape[0] % chunks != 0:
             chunks = 1
         src, tgt, true_prop, src_mask, tgt_mask = self._chunk_inputs(data)
-        x_out, mu, logvar, pred_len, pred_prop = self.model(src, tgt, src_mask, tgt_mask)
+        x_out, mu, logvar, pred_len, pred_prop = self._model_forward(src, tgt, src_mask, tgt_mask)
         out5, _ = ops.loss_fwd_bwd(src, x_out, self.params['CHAR_WEIGHTS'], pred_len, mu, logvar, pred_prop,
                                    true_prop, beta, self.pad_idx, want_grads=False, n_groups=chunks)
         return out5.view(chunks, 5)
@@ -782,6 +799,8 @@ class VAEShell():
         dev = self._device()
         mem = mem.to(dev).float()
         n = mem.shape[0]
+        if self.model_type != 'transformer':
+            return self._rnn_greedy_decode(mem, condition)
         if src_mask is None:
             lens = self.model.encoder.predict_mask_length(mem)            # (n, 1) int64, may be 0
             key_mask = (torch.arange(self.src_len + 1, device=dev)[None, :] < lens).to(torch.uint8).contiguous()
@@ -797,6 +816,39 @@ class VAEShell():
                 mem, key_mask, self.params['CHAR_DICT']['<start>'], cond, self.tgt_len)
         finally:
             self.model.train(was_training)
+
+    @torch.no_grad()
+    def _rnn_greedy_decode(self, mem, condition=[]):
+        """Greedy decoding of the RNN models.  The reference re-runs the whole decoder over the 126-token buffer for every
+        new token and reads position i (:425-431); a GRU is causal, so the same tokens come from ONE pass that carries
+        the hidden states from step to step: per step the embedded previous token and memory row i go through one GRU
+        step per layer, then norm -> generator -> arg max."""
+        dev = self._device()
+        model = self.model
+        was_training = model.training
+        model.eval()
+        try:
+            dec = model.decoder
+            n, max_len = mem.shape[0], self.tgt_len
+            rows = dec.expand_memory(mem)                                   # (n, 126, size)
+            tgt = torch.full((n, max_len + 1), self.params['CHAR_DICT']['<start>'], dtype=torch.long, device=dev)
+            for j, tok in enumerate(condition):
+                tgt[:, j + 1] = self.params['CHAR_DICT'][tok]
+            h = [torch.zeros((n, dec.size), device=dev) for _ in range(dec.n_layers)]
+            nxt = torch.empty(n, dtype=torch.int32, device=dev)
+            for i in range(max_len):
+                x = rows[:, i, :]
+                if dec.teacher_force:
+                    x = torch.cat((model.src_embed(tgt[:, i:i + 1])[:, 0, :], x), dim=1)
+                h = dec.gru.step(x.contiguous(), h)
+                if i >= len(condition):
+                    logits = model.generator(dec.norm(h[-1]))
+                    ops.call("tvae_argmax_rows", ops._p(logits), logits.stride(0), logits.shape[1], ops._p(nxt), n,
+                             ops._stream())
+                    tgt[:, i + 1] = nxt.long() + 1
+            return tgt[:, 1:]
+        finally:
+            model.train(was_training)
 
     def _encode_batches(self, data):
         "yield (offset, chunk data, src, src_mask) over full batches, as reconstruct / calc_mems iterate (reference :459-483)"
@@ -824,7 +876,7 @@ class VAEShell():
                 with open('calcs/{}_progress.txt'.format(self.name), 'a') as f:
                     f.write('{}\n'.format(j))
                 last_j = j
-            _, mem, _, _ = self.model.encode(src, src_mask)      # reference quirk: keeps mu as "mem" (:487)
+            _, mem, _ = self._encode(src, src_mask)              # reference quirk: keeps mu as "mem" (:487)
             mems[off:off + mem.shape[0]] = mem.cpu()
             decoded = self.greedy_decode(mem, src_mask=src_mask) if method == 'greedy' else None
             if return_str:
@@ -854,7 +906,7 @@ class VAEShell():
                 with open('memory/{}_progress.txt'.format(self.name), 'a') as f:
                     f.write('{}\n'.format(j))
                 last_j = j
-            mem, mu, logvar, _ = self.model.encode(src, src_mask)
+            mem, mu, logvar = self._encode(src, src_mask)
             for buf, t in zip(out, (mem, mu, logvar)):
                 buf[off:off + t.shape[0]] = t.cpu()
         mems, mus, logvars = (t.numpy() for t in out)

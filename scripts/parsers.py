@@ -1,6 +1,6 @@
 """Command-line flags of the TransVAE scripts (same names and defaults as the reference's
 scripts/parsers.py:36-122, so existing job files keep working) and the small loaders the scripts share.
-Only the transformer VAE is built here (`--model transvae`); the GRU models are out of scope."""
+All three model families are built: `--model transvae | rnnattn | rnn`; the attention dump is the transformer's."""
 import argparse
 import io
 import json
@@ -9,6 +9,7 @@ import pickle
 import numpy as np
 
 from transvae_amd import synth
+from transvae_amd.rnn_models import RNN, RNNAttn
 from transvae_amd.trans_models import TransVAE
 from transvae_amd.tvae_util import build_org_dict
 
@@ -79,23 +80,34 @@ def vocab_parser():
 
 
 def require_transformer(args):
+    "scripts/attention.py: the weights it dumps are those of the transformer's attention layers"
     if args.model != 'transvae':
-        raise SystemExit("transvae_amd builds the transformer VAE only (--model transvae); "
-                         "'%s' is outside this build's scope" % args.model)
+        raise SystemExit("the attention dump covers the transformer VAE (--model transvae); for '%s' use "
+                         "RNNAttnEncoder.forward(x, return_attn=True)" % args.model)
 
 
 def default_save_name(args):
-    "trans{d_ff/d_model}x-{d_model}_{source} (reference scripts/parsers.py:7-17)"
+    "trans{d_ff/d_model}x-{d_model}_{source}, or {model}-{d_model}_{source} for the RNN models (reference scripts/parsers.py:7-17)"
     if args.save_name is not None:
         return args.save_name
-    return 'trans{}x-{}_{}'.format(args.d_feedforward // args.d_model, args.d_model, args.data_source)
+    if args.model == 'transvae':
+        return 'trans{}x-{}_{}'.format(args.d_feedforward // args.d_model, args.d_model, args.data_source)
+    return '{}-{}_{}'.format(args.model, args.d_model, args.data_source)
 
 
 def model_init(args, params={}):
-    require_transformer(args)
-    return TransVAE(params=params, name=default_save_name(args), d_model=args.d_model, d_ff=args.d_feedforward,
-                    d_latent=args.d_latent, property_predictor=args.property_predictor,
-                    d_pp=args.d_property_predictor, depth_pp=args.depth_property_predictor)
+    "the model class --model names, built from the flags (reference scripts/parsers.py:19-34)"
+    common = dict(params=params, name=default_save_name(args), d_model=args.d_model, d_latent=args.d_latent,
+                  property_predictor=args.property_predictor, d_pp=args.d_property_predictor,
+                  depth_pp=args.depth_property_predictor)
+    if args.model == 'transvae':
+        return TransVAE(d_ff=args.d_feedforward, **common)
+    return {'rnnattn': RNNAttn, 'rnn': RNN}[args.model](**common)
+
+
+def model_load(model, ckpt_fn):
+    "the model class --model names, restored from a checkpoint (reference scripts/sample.py:15-21)"
+    return {'transvae': TransVAE, 'rnnattn': RNNAttn, 'rnn': RNN}[model](load_fn=ckpt_fn)
 
 
 class _PlainUnpickler(pickle.Unpickler):

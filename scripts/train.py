@@ -1,4 +1,4 @@
-"""Train a TransVAE on MI355X (flags: scripts/parsers.py; behaviour: reference scripts/train.py:14-84).
+"""Train a TransVAE / RNNAttn / RNN on MI355X (flags: scripts/parsers.py; behaviour: reference scripts/train.py:14-84).
 
     python scripts/train.py --model transvae --d_model 256 --d_feedforward 1024 --data_source zinc
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 scripts/train.py ...   # data parallel
@@ -11,7 +11,7 @@ import pandas as pd
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from scripts.parsers import load_vocab, model_init, require_transformer, train_parser  # noqa: E402
+from scripts.parsers import load_vocab, model_init, train_parser  # noqa: E402
 from transvae_amd import ops  # noqa: E402
 from transvae_amd.trans_models import _load_checkpoint  # noqa: E402
 
@@ -21,7 +21,6 @@ def _read_column_file(path):
 
 
 def train(args):
-    require_transformer(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world > 1:
         import torch.distributed as dist

@@ -37,8 +37,12 @@ def _build(batch, chunks):
     from transvae_amd import synth
     from transvae_amd.trans_models import TransVAE
     cd, od, w = synth.load_vocab("zinc")
-    vae = TransVAE(params={"CHAR_DICT": cd, "ORG_DICT": od, "CHAR_WEIGHTS": w, "BATCH_SIZE": batch,
-                           "BATCH_CHUNKS": chunks}, name="dp", **synth.ARCHS[ARCH])
+    params = {"CHAR_DICT": cd, "ORG_DICT": od, "CHAR_WEIGHTS": w, "BATCH_SIZE": batch, "BATCH_CHUNKS": chunks}
+    if ARCH == "rnnattn-128":           # the recurrent family: AdamOpt, no length head, one parameter (tgt_embed) never used
+        from transvae_amd.rnn_models import RNNAttn
+        vae = RNNAttn(params=params, name="dp", d_model=128, N=2)
+    else:
+        vae = TransVAE(params=params, name="dp", **synth.ARCHS[ARCH])
     vae.model.load_state_dict(synth.synth_state_dict(vae.model.state_dict(), 0))
     vae.model.eval()                    # dropout off: the step is a deterministic function of (data, eps)
     return vae
@@ -80,6 +84,7 @@ def _worker(rank, world, port, reduce, overlap, q, case=("trans1x-128", 8, 2)):
 
 @pytest.mark.parametrize("reduce,overlap,case", [("sum", True, ("trans1x-128", 8, 2)), ("mean", True, ("trans1x-128", 8, 2)),
                                                  ("sum", False, ("trans1x-128", 8, 2)),
+                                                 ("mean", True, ("rnnattn-128", 8, 2)),
                                                  # BASELINE config 3's model at the reference's chunk size: trans4x-256, 100 per rank
                                                  ("mean", True, ("trans4x-256", 100, 1))])
 def test_two_ranks_equal_one_process_on_the_global_batch(reduce, overlap, case):

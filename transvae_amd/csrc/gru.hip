@@ -7,7 +7,7 @@
 //     n = tanh(gi_n + r * gh_n)                          h_t = (1 - z) * n + z * h_{t-1}
 // The recurrent part is what this file does: one launch per time step that fuses the [B, H] x [H, 3H] product with the gate
 // arithmetic.  Batch rows are independent and the hidden units of one step are independent, so a step is a grid of
-// 16-row x 16-unit tiles; the four waves of a workgroup split K (each lane reads whole 64-byte runs of its operand rows
+// 32-row x 16-unit tiles; the four waves of a workgroup split K (each lane reads whole 64-byte runs of its operand rows
 // straight into MFMA operand registers -- v_mfma_f32_16x16x4_f32 takes any k order as long as A and B agree), add their
 // partial tiles through LDS, and every thread then finishes one (row, unit).  The backward step is the same product shape
 // against W_hh^T (K = 3H) fused with the gate derivatives; weight gradients are left to two large GEMMs over all steps.
@@ -32,109 +32,164 @@ struct GruArgs {
 
 __device__ inline float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
-// partial[g][r] of this wave: rows 4 * (lane / 16) + r, unit lane % 16, over the wave's quarter of K.
-// A rows are `lda` floats apart, rows of W `ldw`; NG accumulators use W rows u0 + g * gstride + j.
-template <int NG>
+constexpr int RS = 2;                    // 16-row sub-tiles per workgroup: a step's tile is 32 rows x 16 units
+
+// partial[s][g][r] of this wave: rows 16 s + 4 * (lane / 16) + r, unit lane % 16, over the wave's quarter of K.
+// A rows are `lda` floats apart, rows of W `ldw`; NG accumulators per sub-tile use W rows u0 + g * gstride + j.
+// A step is bound by what a CU can pull in from L2 (measured ~26 GB/s per CU), so a workgroup covers 32 rows with one
+// read of its W rows (16 x 16 tiles moved 1.6x the bytes per CU), and every operand byte of a batch of CH float4 per row is
+// requested before the first MFMA of the batch is issued (one L2 round trip per batch, not one per float4).
+template <int NG, int CH>
 __device__ inline void tile_product(const float* __restrict__ A, long lda, int rows_valid, const float* __restrict__ W, int ldw,
-                                    int gstride, int K, int wave, int lane, floatx4 (&acc)[NG]) {
+                                    int gstride, int K, int wave, int lane, floatx4 (&acc)[RS][NG]) {
   const int i = lane & 15, kq = lane >> 4;
   const int kw = K >> 2;                 // this wave's share of K
   const int kl = kw >> 2;                // floats per lane: a contiguous run
-  const float* ap = A + (long)(i < rows_valid ? i : 0) * lda + wave * kw + kq * kl;
+  const int nch = kl >> 2;               // float4 per lane
+  const float* ap[RS];
+#pragma unroll
+  for (int s = 0; s < RS; ++s) ap[s] = A + (long)(16 * s + i < rows_valid ? 16 * s + i : 0) * lda + wave * kw + kq * kl;
   const float* wp = W + (long)i * ldw + wave * kw + kq * kl;
-  for (int c = 0; c < kl; c += 4) {
-    const float4 a = *reinterpret_cast<const float4*>(ap + c);
-    float4 b[NG];
+  for (int c0 = 0; c0 < nch; c0 += CH) {
+    float4 a[RS][CH], b[NG][CH];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) b[g] = *reinterpret_cast<const float4*>(wp + (long)g * gstride * ldw + c);
+    for (int c = 0; c < CH; ++c) {
+      const int cc = (c0 + c < nch) ? c0 + c : c0;            // past the end: repeat a valid chunk, skipped below
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[g].x, acc[g], 0, 0, 0);
-      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[g].y, acc[g], 0, 0, 0);
-      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[g].z, acc[g], 0, 0, 0);
-      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[g].w, acc[g], 0, 0, 0);
+      for (int s = 0; s < RS; ++s) a[s][c] = *reinterpret_cast<const float4*>(ap[s] + 4 * cc);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) b[g][c] = *reinterpret_cast<const float4*>(wp + (long)g * gstride * ldw + 4 * cc);
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if (c0 + c < nch) {
+#pragma unroll
+        for (int s = 0; s < RS; ++s)
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            acc[s][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][c].x, b[g][c].x, acc[s][g], 0, 0, 0);
+            acc[s][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][c].y, b[g][c].y, acc[s][g], 0, 0, 0);
+            acc[s][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][c].z, b[g][c].z, acc[s][g], 0, 0, 0);
+            acc[s][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][c].w, b[g][c].w, acc[s][g], 0, 0, 0);
+          }
+      }
     }
   }
 }
 
-// sum over the four waves of accumulator g for thread tid's (row i = tid / 16, unit j = tid % 16)
+// sum over the four waves of accumulator (s, g) for thread tid's rows 16 s + tid / 16, unit tid % 16
 template <int NG>
-__device__ inline void reduce_tiles(floatx4 (&acc)[NG], float* red, int wave, int lane, int tid, float (&out)[NG]) {
+__device__ inline void reduce_tiles(floatx4 (&acc)[RS][NG], float* red, int wave, int lane, int tid, float (&out)[RS][NG]) {
 #pragma unroll
-  for (int g = 0; g < NG; ++g)
+  for (int s = 0; s < RS; ++s)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[((wave * NG + g) * 4 + r) * 64 + lane] = acc[g][r];
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(((wave * RS + s) * NG + g) * 4 + r) * 64 + lane] = acc[s][g][r];
   __syncthreads();
   const int i = tid >> 4, j = tid & 15;
   const int src = 16 * (i >> 2) + j, r = i & 3;
 #pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    float s = 0.f;
+  for (int s = 0; s < RS; ++s)
 #pragma unroll
-    for (int w = 0; w < 4; ++w) s += red[((w * NG + g) * 4 + r) * 64 + src];
-    out[g] = s;
-  }
+    for (int g = 0; g < NG; ++g) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) t += red[(((w * RS + s) * NG + g) * 4 + r) * 64 + src];
+      out[s][g] = t;
+    }
 }
 
 __global__ __launch_bounds__(256) void gru_fwd_step(GruArgs a) {
-  __shared__ float red[4 * 3 * 4 * 64];
+  __shared__ float red[4 * RS * 3 * 4 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b0 = blockIdx.x * 16, u0 = blockIdx.y * 16;
+  const int b0 = blockIdx.x * 16 * RS, u0 = blockIdx.y * 16;
   const int H = a.H, t = a.t;
-  const long rowstep = (long)a.sb;       // rows between consecutive batch entries at one time step
   const float* hprev_base = t > 0 ? a.hseq + ((long)b0 * a.sb + (long)(t - 1) * a.st) * H : (a.h0 ? a.h0 + (long)b0 * H : nullptr);
-  const long hprev_ld = t > 0 ? rowstep * H : H;
-  floatx4 acc[3];
+  const long hprev_ld = t > 0 ? (long)a.sb * H : H;
+  // this thread's (rows, unit) and everything its gate arithmetic reads: requested before the product, used after it
+  const int i = tid >> 4, j = tid & 15, u = u0 + j;
+  const float br = a.b_hh[u], bz = a.b_hh[H + u], bn = a.b_hh[2 * H + u];
+  bool live[RS];
+  long row[RS];
+  float gir[RS], giz[RS], gin[RS], hp[RS];
 #pragma unroll
-  for (int g = 0; g < 3; ++g) acc[g] = floatx4{0.f, 0.f, 0.f, 0.f};
-  if (hprev_base) tile_product<3>(hprev_base, hprev_ld, a.B - b0, a.w + (long)u0 * H, H, H, H, wave, lane, acc);
-  float gh[3];
+  for (int s = 0; s < RS; ++s) {
+    const int b = b0 + 16 * s + i;
+    live[s] = b < a.B;
+    row[s] = (long)(live[s] ? b : b0) * a.sb + (long)t * a.st;
+    const float* gi = a.gi + row[s] * 3 * H;
+    gir[s] = gi[u]; giz[s] = gi[H + u]; gin[s] = gi[2 * H + u];
+    hp[s] = hprev_base ? hprev_base[(long)(live[s] ? 16 * s + i : 0) * hprev_ld + u] : 0.f;
+  }
+  floatx4 acc[RS][3];
+#pragma unroll
+  for (int s = 0; s < RS; ++s)
+#pragma unroll
+    for (int g = 0; g < 3; ++g) acc[s][g] = floatx4{0.f, 0.f, 0.f, 0.f};
+  if (hprev_base) tile_product<3, 4>(hprev_base, hprev_ld, a.B - b0, a.w + (long)u0 * H, H, H, H, wave, lane, acc);
+  float gh[RS][3];
   reduce_tiles<3>(acc, red, wave, lane, tid, gh);
-  const int i = tid >> 4, j = tid & 15, b = b0 + i, u = u0 + j;
-  if (b >= a.B) return;
-  const long row = (long)b * a.sb + (long)t * a.st;
-  const float* gi = a.gi + row * 3 * H;
-  const float hr = gh[0] + a.b_hh[u], hz = gh[1] + a.b_hh[H + u], hn = gh[2] + a.b_hh[2 * H + u];
-  const float r = sigmoidf_(gi[u] + hr), z = sigmoidf_(gi[H + u] + hz);
-  const float n = tanhf(gi[2 * H + u] + r * hn);
-  const float hp = hprev_base ? hprev_base[(long)i * hprev_ld + u] : 0.f;
-  a.hseq[row * H + u] = (1.f - z) * n + z * hp;
-  if (a.gates) {
-    float* G = a.gates + row * 4 * H;
-    G[u] = r; G[H + u] = z; G[2 * H + u] = n; G[3 * H + u] = hn;
+#pragma unroll
+  for (int s = 0; s < RS; ++s) {
+    if (!live[s]) continue;
+    const float hr = gh[s][0] + br, hz = gh[s][1] + bz, hn = gh[s][2] + bn;
+    const float r = sigmoidf_(gir[s] + hr), z = sigmoidf_(giz[s] + hz);
+    const float n = tanhf(gin[s] + r * hn);
+    a.hseq[row[s] * H + u] = (1.f - z) * n + z * hp[s];
+    if (a.gates) {
+      float* G = a.gates + row[s] * 4 * H;
+      G[u] = r; G[H + u] = z; G[2 * H + u] = n; G[3 * H + u] = hn;
+    }
   }
 }
 
 __global__ __launch_bounds__(256) void gru_bwd_step(GruArgs a) {
-  __shared__ float red[4 * 1 * 4 * 64];
+  __shared__ float red[4 * RS * 1 * 4 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b0 = blockIdx.x * 16, u0 = blockIdx.y * 16;
+  const int b0 = blockIdx.x * 16 * RS, u0 = blockIdx.y * 16;
   const int H = a.H, t = a.t;
-  floatx4 acc[1] = {floatx4{0.f, 0.f, 0.f, 0.f}};
   const bool last = t == a.T - 1;
+  const int i = tid >> 4, j = tid & 15, u = u0 + j;
+  bool live[RS];
+  long row[RS], bb[RS];
+  float dh[RS], r[RS], z[RS], n[RS], hn[RS], hp[RS];
+  // the gate derivatives' inputs: requested before the product
+#pragma unroll
+  for (int s = 0; s < RS; ++s) {
+    const int b = b0 + 16 * s + i;
+    live[s] = b < a.B;
+    bb[s] = live[s] ? b : b0;
+    row[s] = bb[s] * a.sb + (long)t * a.st;
+    dh[s] = a.dhseq ? a.dhseq[row[s] * H + u] : 0.f;
+    if (last) dh[s] += a.dh_last ? a.dh_last[bb[s] * H + u] : 0.f;
+    else dh[s] += a.carry[bb[s] * H + u];
+    const float* G = a.gates + row[s] * 4 * H;
+    r[s] = G[u]; z[s] = G[H + u]; n[s] = G[2 * H + u]; hn[s] = G[3 * H + u];
+    hp[s] = t > 0 ? a.hseq[(row[s] - a.st) * H + u] : (a.h0 ? a.h0[bb[s] * H + u] : 0.f);
+  }
+  floatx4 acc[RS][1];
+#pragma unroll
+  for (int s = 0; s < RS; ++s) acc[s][0] = floatx4{0.f, 0.f, 0.f, 0.f};
   if (!last) {
     const float* dgh_next = a.dgh + ((long)b0 * a.sb + (long)(t + 1) * a.st) * 3 * H;
-    tile_product<1>(dgh_next, (long)a.sb * 3 * H, a.B - b0, a.w + (long)u0 * 3 * H, 3 * H, 0, 3 * H, wave, lane, acc);
+    tile_product<1, 6>(dgh_next, (long)a.sb * 3 * H, a.B - b0, a.w + (long)u0 * 3 * H, 3 * H, 0, 3 * H, wave, lane, acc);
   }
-  float back[1];
+  float back[RS][1];
   reduce_tiles<1>(acc, red, wave, lane, tid, back);
-  const int i = tid >> 4, j = tid & 15, b = b0 + i, u = u0 + j;
-  if (b >= a.B) return;
-  const long row = (long)b * a.sb + (long)t * a.st;
-  float dh = a.dhseq ? a.dhseq[row * H + u] : 0.f;
-  if (last) dh += a.dh_last ? a.dh_last[(long)b * H + u] : 0.f;
-  else dh += a.carry[(long)b * H + u] + back[0];
-  const float* G = a.gates + row * 4 * H;
-  const float r = G[u], z = G[H + u], n = G[2 * H + u], hn = G[3 * H + u];
-  const float hp = t > 0 ? a.hseq[(row - a.st) * H + u] : (a.h0 ? a.h0[(long)b * H + u] : 0.f);
-  const float dn = dh * (1.f - z), dz = dh * (hp - n);
-  const float dnp = dn * (1.f - n * n);
-  const float drp = dnp * hn * r * (1.f - r), dzp = dz * z * (1.f - z);
-  float* dgi = a.dgi + row * 3 * H;
-  float* dgh = a.dgh + row * 3 * H;
-  dgi[u] = drp; dgi[H + u] = dzp; dgi[2 * H + u] = dnp;
-  dgh[u] = drp; dgh[H + u] = dzp; dgh[2 * H + u] = dnp * r;
-  a.carry[(long)b * H + u] = dh * z;
+#pragma unroll
+  for (int s = 0; s < RS; ++s) {
+    if (!live[s]) continue;
+    const float d = last ? dh[s] : dh[s] + back[s][0];
+    const float dn = d * (1.f - z[s]), dz = d * (hp[s] - n[s]);
+    const float dnp = dn * (1.f - n[s] * n[s]);
+    const float drp = dnp * hn[s] * r[s] * (1.f - r[s]), dzp = dz * z[s] * (1.f - z[s]);
+    float* dgi = a.dgi + row[s] * 3 * H;
+    float* dgh = a.dgh + row[s] * 3 * H;
+    dgi[u] = drp; dgi[H + u] = dzp; dgi[2 * H + u] = dnp;
+    dgh[u] = drp; dgh[H + u] = dzp; dgh[2 * H + u] = dnp * r[s];
+    a.carry[bb[s] * H + u] = d * z[s];
+  }
 }
 
 // one wave per row: y = softmax(x) / dx = y * (dy - sum(y dy))
@@ -182,7 +237,7 @@ extern "C" int tvae_gru_fwd(const float* gi, const float* w_hh, const float* b_h
   GruArgs a = {};
   a.gi = gi; a.w = w_hh; a.b_hh = b_hh; a.h0 = h0; a.hseq = hseq; a.gates = gates;
   a.T = T; a.B = B; a.H = H; a.sb = time_major ? 1 : T; a.st = time_major ? B : 1;
-  const dim3 grid(cdiv(B, 16), H / 16);
+  const dim3 grid(cdiv(B, 16 * RS), H / 16);
   for (int t = 0; t < T; ++t) {
     a.t = t;
     hipLaunchKernelGGL(gru_fwd_step, grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -202,7 +257,7 @@ extern "C" int tvae_gru_bwd(const float* dhseq, const float* dh_last, const floa
   a.w = w_hh_t; a.h0 = h0; a.hseq = const_cast<float*>(hseq); a.gates = const_cast<float*>(gates);
   a.dhseq = dhseq; a.dh_last = dh_last; a.dgi = dgi; a.dgh = dgh; a.carry = carry;
   a.T = T; a.B = B; a.H = H; a.sb = time_major ? 1 : T; a.st = time_major ? B : 1;
-  const dim3 grid(cdiv(B, 16), H / 16);
+  const dim3 grid(cdiv(B, 16 * RS), H / 16);
   for (int t = T - 1; t >= 0; --t) {
     a.t = t;
     hipLaunchKernelGGL(gru_bwd_step, grid, dim3(256), 0, (hipStream_t)stream, a);

@@ -132,6 +132,37 @@ def roofline_decode_of(n):
                       "(half of the decode's device time; the other half is the fp32 MFMA GEMMs of `roofline`)" % n}
 
 
+def rnn_secondary(kind, d_model, batch=500, steps=5, decode_n=16384):
+    """Secondary figures for SURVEY.md 8(f) row 4: train step and greedy decode of a recurrent model (same synthetic
+    batch shape, dropout on, exact-fp32 recurrence; the input-projection GEMMs follow the selected arithmetic)."""
+    from transvae_amd import ops, rnn_models, synth
+    cd, od, w = synth.load_vocab("zinc")
+    cls = {"rnnattn": rnn_models.RNNAttn, "rnn": rnn_models.RNN}[kind]
+    vae = cls(params={"CHAR_DICT": cd, "ORG_DICT": od, "CHAR_WEIGHTS": w, "BATCH_SIZE": batch, "BATCH_CHUNKS": 5},
+              name="bench_" + kind, d_model=d_model)
+    vae.model.load_state_dict(synth.synth_state_dict(vae.model.state_dict(), 0))
+    vae.model.train()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    data = torch.cat([synth.synth_tokens(batch, seed=1).float(), torch.zeros(batch, 1)], 1).to(dev)
+    for _ in range(3):
+        vae.train_step(data, 0.01)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        vae.train_step(data, 0.01)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    z = torch.randn(decode_n, 128, generator=torch.Generator().manual_seed(0)).to(dev)
+    vae.greedy_decode(z[:64])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    vae.greedy_decode(z)
+    torch.cuda.synchronize()
+    td = time.perf_counter() - t0
+    return {"model": "%s-%d" % (kind, d_model), "train_tokens_per_s": batch * 126 / dt, "ms_per_step": 1e3 * dt,
+            "batch": batch, "decode_mols_per_s": decode_n / td, "decode_batch": decode_n}
+
+
 def cpu_baseline(threads, batch=500, chunks=5):
     """The oracle's train step on host cores, as SURVEY.md 8(d) asks: batch 500 = 5 chunks of 100 molecules, each
     chunk forward + loss + backward with the gradients accumulating, then one Noam/Adam step.  Two figures: dropout
@@ -235,6 +266,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-extra-modes", action="store_true", help="skip the secondary timings in the other GEMM arithmetics")
+    ap.add_argument("--no-rnn", action="store_true", help="skip the secondary figures of the recurrent models")
     ap.add_argument("--no-roofline", action="store_true", help="skip the roofline launches (profiles of the train step alone)")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run nothing but the launches of the roofline kernel (warmed by time, then 50 timed) and print its roofline "
@@ -434,6 +466,10 @@ def main():
             if not args.no_extra_modes and args.dtype != "f32x3":
                 out["roofline_f32x3"] = roofline("f32x3")
         ops.set_compute_dtype(args.dtype)
+        if not args.no_rnn and not args.no_extra_modes and world == 1:
+            del vae
+            torch.cuda.empty_cache()
+            out["recurrent_models"] = [rnn_secondary("rnnattn", 256), rnn_secondary("rnn", 128)]
         if not args.no_cpu_baseline and world == 1:
             threads = min(16, os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(threads)

@@ -124,6 +124,28 @@ __device__ inline void stage_load_fast(float4 (&st)[BK / 8], const float* __rest
     st[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + off[j]);
 }
 
+// A-side dropout mask on a fast-staged tile: the element index of each float4 of a thread is (per-thread constant) +
+// (uniform per k-step), so the per-step work is one add and the keep-scale hash per float4
+template <int BK, bool KM>
+__device__ inline void drop_indices(unsigned (&idx)[BK / 8], int row0, int nrows, int dropM, int dropK, int tid) {
+#pragma unroll
+  for (int j = 0; j < BK / 8; ++j) {
+    int row, k;
+    stage_pos<BK, KM>(tid + 256 * j, row, k);
+    const int gr = min(row0 + row, KM ? nrows - 4 : nrows - 1);      // the clamp of stage_offsets: such rows are never stored
+    idx[j] = KM ? (unsigned)k * (unsigned)dropM + (unsigned)gr : (unsigned)gr * (unsigned)dropK + (unsigned)k;
+  }
+}
+template <int BK>
+__device__ inline void stage_drop_fast(float4 (&st)[BK / 8], const unsigned (&idx)[BK / 8], unsigned kadd, const DropCfg& dc) {
+#pragma unroll
+  for (int j = 0; j < BK / 8; ++j) {
+    float ks[4];
+    drop_scale4(dc, idx[j] + kadd, ks);
+    st[j].x *= ks[0]; st[j].y *= ks[1]; st[j].z *= ks[2]; st[j].w *= ks[3];
+  }
+}
+
 template <int BK, bool KM, bool DROP>
 __device__ inline void stage_fix(float4 (&st)[BK / 8], int row0, int nrows, int k0, int kend, int tid,
                                  const DropCfg& dc, int dropM, int dropK) {
@@ -181,7 +203,7 @@ __device__ inline void stage_store_bf16(const float4 (&st)[BK / 8], unsigned sho
 template <int BK, bool A_KM, bool B_KM, bool ALIGNED, bool BF16, bool DROP, bool FAST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BK == 16 ? 4 : 2)))
 void gemm_kernel(GemmArgs g) {
-  static_assert(!FAST || (ALIGNED && !DROP), "fast staging: aligned operands, no A-side dropout mask");
+  static_assert(!FAST || ALIGNED, "fast staging: aligned operands");
   if (gridDim.y > 1) {   // tvae_gemm_batched: one matrix product per blockIdx.y
     const long by = blockIdx.y;
     g.A += by * g.sA; g.B += by * g.sB; g.C += by * g.sC;
@@ -226,10 +248,11 @@ void gemm_kernel(GemmArgs g) {
   auto tileA = [&](int buf) { return lds + (buf * 2 + 0) * TILE_FLOATS; };
   auto tileB = [&](int buf) { return lds + (buf * 2 + 1) * TILE_FLOATS; };
 
-  unsigned offA[FAST ? NJ : 1], offB[FAST ? NJ : 1];
+  unsigned offA[FAST ? NJ : 1], offB[FAST ? NJ : 1], didx[(FAST && DROP) ? NJ : 1];
   if constexpr (FAST) {
     stage_offsets<BK, A_KM>(offA, g.lda, m0, g.M, tid);
     stage_offsets<BK, B_KM>(offB, g.ldb, n0, g.N, tid);
+    if constexpr (DROP) drop_indices<BK, A_KM>(didx, m0, g.M, g.M, g.K, tid);
   }
   // loads of the k-step that starts at k0 (only issued; see stage_load) / what must happen to the registers before the LDS store
   auto load_step = [&](int k0, bool checked) {
@@ -244,7 +267,10 @@ void gemm_kernel(GemmArgs g) {
     stage_load<BK, B_KM, ALIGNED>(sb, g.B, g.ldb, n0, g.N, k0, kend, tid);
   };
   auto fix_step = [&](int k0, bool checked) {
-    if (FAST && !checked) return;
+    if (FAST && !checked) {
+      if constexpr (FAST && DROP) stage_drop_fast<BK>(sa, didx, A_KM ? (unsigned)k0 * (unsigned)g.M : (unsigned)k0, dc);
+      return;
+    }
     stage_fix<BK, A_KM, DROP>(sa, m0, g.M, k0, kend, tid, dc, g.M, g.K);
     stage_fix<BK, B_KM, false>(sb, n0, g.N, k0, kend, tid, nodrop, 0, 0);
   };
@@ -380,7 +406,12 @@ void gemm_kernel(GemmArgs g) {
 template <int BK, bool A_KM, bool B_KM, bool ALIGNED, bool BF16>
 void launch2(const GemmArgs& g, dim3 grid, hipStream_t s, bool drop) {
   if (drop) {
-    hipLaunchKernelGGL((gemm_kernel<BK, A_KM, B_KM, ALIGNED, BF16, true, false>), grid, dim3(256), 0, s, g);
+    if constexpr (ALIGNED) {
+      if (g.flags & FLAG_FAST_STAGE) hipLaunchKernelGGL((gemm_kernel<BK, A_KM, B_KM, true, BF16, true, true>), grid, dim3(256), 0, s, g);
+      else hipLaunchKernelGGL((gemm_kernel<BK, A_KM, B_KM, true, BF16, true, false>), grid, dim3(256), 0, s, g);
+    } else {
+      hipLaunchKernelGGL((gemm_kernel<BK, A_KM, B_KM, ALIGNED, BF16, true, false>), grid, dim3(256), 0, s, g);
+    }
   } else if constexpr (ALIGNED) {
     if (g.flags & FLAG_FAST_STAGE) hipLaunchKernelGGL((gemm_kernel<BK, A_KM, B_KM, true, BF16, false, true>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((gemm_kernel<BK, A_KM, B_KM, true, BF16, false, false>), grid, dim3(256), 0, s, g);

@@ -23,6 +23,8 @@ if kt:
     for r in csv.DictReader(open(kt[0])):
         dur[r["Dispatch_Id"]] = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-9
 ids = sorted(by, key=int)[2:]
+if len(ids) > 12:
+    ids = ids[:3] + ids[-6:]          # a long run: the first launches (cold clock) and the last ones
 for d in ids:
     c = by[d]
     t = dur.get(d)

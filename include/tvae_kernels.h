@@ -106,13 +106,18 @@ int tvae_gemm_batched(const float* A, int lda, long strideA, const float* B, int
  *        The caller finishes with plain GEMMs: dx = dgi W_ih, dW_ih = dgi^T x, db_ih = colsum dgi,
  *        dW_hh = dgh[:, 1:]^T hseq[:, :-1] (+ dgh[:, 0]^T h0), db_hh = colsum dgh.  The gradient of h0 is not produced
  *        (the reference always starts from zeros, rnn_models.py:262-263).
+ * A sequence may be processed in time CHUNKS (time-major buffers, pointers advanced by t0 * B rows, h0 = the rows of step
+ * t0 - 1): forward chunks in ascending order; backward chunks in descending order with `continues` = 1 on every chunk but
+ * the one that holds the last time step (the call then takes the step after its last from the dgh rows that follow its
+ * own and from `carry`, which the later chunk's call left).  That is what lets the layers of a stack run as a pipeline on
+ * separate streams (ops.GRUStackFn).
  * H must be a multiple of 64.
  */
 int tvae_gru_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h0, float* hseq, float* gates,
                  int T, int B, int H, int time_major, void* stream);
 int tvae_gru_bwd(const float* dhseq, const float* dh_last, const float* hseq, const float* gates, const float* h0,
                  const float* w_hh_t, float* dgi, float* dgh, float* carry, int T, int B, int H, int time_major,
-                 void* stream);
+                 int continues, void* stream);
 
 /*
  * Row softmax y = softmax(x) over n columns and its backward dx = y * (dy - sum(y dy)): the attention weights of

@@ -62,7 +62,7 @@ def test_gru_rejects_bad_shapes():
     with pytest.raises(_lib.TvaeError):
         ops.call("tvae_gru_fwd", ops._p(a), ops._p(a), ops._p(a), None, ops._p(a), None, 1, 1, 48, 1, ops._stream())
     with pytest.raises(_lib.TvaeError):
-        ops.call("tvae_gru_bwd", None, None, ops._p(a), ops._p(a), None, ops._p(a), ops._p(a), ops._p(a), ops._p(a), 1, 1, 64, 1,
+        ops.call("tvae_gru_bwd", None, None, ops._p(a), ops._p(a), None, ops._p(a), ops._p(a), ops._p(a), ops._p(a), 1, 1, 64, 1, 0,
                  ops._stream())
 
 
@@ -185,11 +185,18 @@ def test_rnn_adamopt_steps_match_reference(name):
         for k in g["keys"]:
             want = g["p_step%d/%s" % (step + 1, k)]
             got = named[str(k)].detach().cpu().numpy()[:6]
-            # Adam's update is lr * m / (sqrt(v) + eps) ~ lr per element: compare the parameters to a small part of lr
-            # (elements whose gradient is of the size of Adam's eps = 1e-8, e.g. attention-logit biases of positions that
-            # are hardly attended, turn a 1e-9 gradient difference into percents of lr)
-            # and the weights that differ after one step move the next step's gradients: the bar grows with the step)
-            assert np.abs(got - want).max() < 0.05 * (step + 1) * float(g["lr"]), (step, k, np.abs(got - want).max())
+            # Adam's update is lr * m / (sqrt(v) + eps) ~ lr per element: compare the parameters to a small part of lr.
+            # Single elements can be ill-conditioned (a gradient of the size of Adam's eps, or one that changes sign between
+            # steps so that m is small beside sqrt(v); weights that differ after one step move the next step's gates), and
+            # how much is MEASURED: the golden also holds the reference's own float64 run of the same three steps, and the
+            # bar follows the distance between its float32 and float64 runs (rnnattn-256, encoder side: median 0.05 lr).
+            # A wrong beta, eps or bias correction moves EVERY element by >= 0.1 lr on every tensor.
+            ref64 = g["p64_step%d/%s" % (step + 1, k)][:6]
+            noise = np.abs(want.astype(np.float64) - ref64).ravel()
+            diff = np.abs(got - want).ravel()
+            lr = float(g["lr"])
+            assert np.median(diff) < max(0.02 * lr, 3 * float(np.median(noise))), (step, k, np.median(diff), np.median(noise))
+            assert diff.max() < max(0.05 * (step + 1) * lr, 6 * float(noise.max())), (step, k, diff.max(), noise.max())
 
 
 def test_rnn_fused_chunks_equal_chunk_loop_and_dropout_trains():

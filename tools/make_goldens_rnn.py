@@ -201,40 +201,54 @@ def golden_step(rm, loss_mod, name):
 
 
 def golden_adam(rm, loss_mod, name):
-    "3 optimizer steps of 2 accumulated chunks each (AdamOpt over torch.optim.Adam, rnn_models.py:105-106), eval mode"
+    """3 optimizer steps of 2 accumulated chunks each (AdamOpt over torch.optim.Adam, rnn_models.py:105-106), eval mode,
+    run by the reference in float32 (the golden) AND in float64: the distance between the two runs is how well-conditioned
+    each recorded parameter element is (Adam's m / sqrt(v) amplifies gradient noise where a gradient changes sign between
+    steps), and the test's bar follows it."""
     from transvae_amd import synth
-    vae = build(rm, name, ADAM_LR=1e-4)
-    keys = [k for k in ("generator.proj.bias", "encoder.norm.a_2", "encoder.gru.bias_hh_l0", "decoder.gru.weight_hh_l1",
-                        "encoder.z_means.bias", "src_embed.lut.weight", "encoder.attn.bias", "decoder.unbottleneck.bias")
-            if k in dict(vae.model.named_parameters())]
-    rec = {"keys": np.array(keys), "lr": np.float64(1e-4)}
-    rng = np.random.default_rng(23)
-    named = dict(vae.model.named_parameters())
-    all_toks, all_eps, losses = [], [], []
-    for step in range(3):
-        vae.model.zero_grad()
-        for c in range(2):
-            toks = synth.synth_tokens(6, seed=300 + 10 * step + c)
-            eps = torch.from_numpy(rng.standard_normal((6, 128)).astype(np.float32))
-            all_toks.append(toks.numpy().astype(np.int8))
-            all_eps.append(eps.numpy())
-            vae.model.eval()
-            src, tgt = toks.long(), toks[:, :-1].long()
-            orig = torch.randn_like
-            torch.randn_like = lambda t, *a, **k: eps.to(t.dtype)
-            try:
-                x_out, mu, logvar, pred_prop = vae.model(src, tgt, None, None)
-            finally:
-                torch.randn_like = orig
-            out = loss_mod.vae_loss(src, x_out, mu, logvar, torch.zeros(6), pred_prop, vae.params["CHAR_WEIGHTS"], 0.01)
-            losses.append(float(out[0]))
-            out[0].backward()
-        vae.optimizer.step()
-        for k in keys:
-            rec["p_step%d/%s" % (step + 1, k)] = named[k].detach().numpy()[:6].copy()      # matrices: first 6 rows
-    rec.update(tokens=np.stack(all_toks), eps=np.stack(all_eps), losses=np.array(losses), beta=np.float64(0.01))
+    rec = {"lr": np.float64(1e-4)}
+    for tag, dtype in (("p", torch.float32), ("p64", torch.float64)):
+        vae = build(rm, name, ADAM_LR=1e-4)
+        vae.model.to(dtype)
+        _follow_dtype(vae.model, dtype)
+        # the optimizer was built over the float32 parameters: rebuild it over the converted ones, as the shell does
+        vae.optimizer = type(vae.optimizer)([p for p in vae.model.parameters() if p.requires_grad], 1e-4, torch.optim.Adam)
+        keys = [k for k in ("generator.proj.bias", "encoder.norm.a_2", "encoder.gru.bias_hh_l0", "decoder.gru.weight_hh_l1",
+                            "encoder.z_means.bias", "src_embed.lut.weight", "encoder.attn.bias", "decoder.unbottleneck.bias")
+                if k in dict(vae.model.named_parameters())]
+        rec["keys"] = np.array(keys)
+        rng = np.random.default_rng(23)
+        named = dict(vae.model.named_parameters())
+        all_toks, all_eps, losses = [], [], []
+        w = vae.params["CHAR_WEIGHTS"].to(dtype)
+        for step in range(3):
+            vae.model.zero_grad()
+            for c in range(2):
+                toks = synth.synth_tokens(6, seed=300 + 10 * step + c)
+                eps = torch.from_numpy(rng.standard_normal((6, 128)).astype(np.float32))
+                all_toks.append(toks.numpy().astype(np.int8))
+                all_eps.append(eps.numpy())
+                vae.model.eval()
+                src, tgt = toks.long(), toks[:, :-1].long()
+                orig = torch.randn_like
+                torch.randn_like = lambda t, *a, **k: eps.to(t.dtype)
+                try:
+                    x_out, mu, logvar, pred_prop = vae.model(src, tgt, None, None)
+                finally:
+                    torch.randn_like = orig
+                out = loss_mod.vae_loss(src, x_out, mu, logvar, torch.zeros(6, dtype=dtype), pred_prop, w, 0.01)
+                losses.append(float(out[0]))
+                out[0].backward()
+            vae.optimizer.step()
+            for k in keys:
+                rec["%s_step%d/%s" % (tag, step + 1, k)] = named[k].detach().numpy()[:6].copy()      # matrices: first 6 rows
+        if tag == "p":
+            rec.update(tokens=np.stack(all_toks), eps=np.stack(all_eps), losses=np.array(losses), beta=np.float64(0.01))
+        print("adam", name, tag, losses)
     np.savez_compressed(os.path.join(OUT, "rnn_adam_%s.npz" % name), **rec)
-    print("adam", name, losses)
+    for k in rec["keys"]:
+        dd = np.abs(rec["p_step3/%s" % k].astype(np.float64) - rec["p64_step3/%s" % k])
+        print("   %-32s reference fp32 vs fp64 after 3 steps: median %.2e max %.2e (lr 1e-4)" % (k, np.median(dd), dd.max()))
 
 
 def golden_decode(rm, name, n=16):

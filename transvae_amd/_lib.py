@@ -26,7 +26,7 @@ SIGNATURES = {
     "tvae_gemm": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _f, _i, _vp, _u, _f, _vp, _i, _vp],
     "tvae_gemm_batched": [_vp, _i, _l, _vp, _i, _l, _vp, _i, _l, _i, _i, _i, _i, _vp, _vp, _i, _l, _f, _i, _vp],
     "tvae_gru_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    "tvae_gru_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "tvae_gru_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "tvae_softmax_rows_fwd": [_vp, _i, _vp, _i, _i, _i, _vp],
     "tvae_softmax_rows_bwd": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp],
     "tvae_split3": [_vp, _i, _vp, _vp, _i, _i, _vp],

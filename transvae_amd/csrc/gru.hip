@@ -28,6 +28,7 @@ struct GruArgs {
   float* dgh;           // bwd: [B, T, 3H] gradient of gh  (dr_pre, dz_pre, dn_pre * r)
   float* carry;         // bwd: [B, H] dh_{t+1} * z_{t+1}
   int T, B, H, sb, st, t;
+  int continues;        // bwd: the step after the last one of this call exists (its dgh rows and the carry are valid)
 };
 
 __device__ inline float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
@@ -48,17 +49,20 @@ __device__ inline void tile_product(const float* __restrict__ A, long lda, int r
   const int nch = kl >> 2;               // float4 per lane
   const float* ap[RS];
 #pragma unroll
-  for (int s = 0; s < RS; ++s) ap[s] = A + (long)(16 * s + i < rows_valid ? 16 * s + i : 0) * lda + wave * kw + kq * kl;
-  const float* wp = W + (long)i * ldw + wave * kw + kq * kl;
+  // k order: float4 c of lane-quarter kq is k = 16 c + 4 kq .. + 3 of the wave's share, so that ONE load instruction reads a
+  // contiguous 64-byte run per row (16 runs per instruction; with each lane walking its own run it touched 32-64 cache lines
+  // per instruction, 16 bytes from each, and the texture path's line rate bounded the step)
+  for (int s = 0; s < RS; ++s) ap[s] = A + (long)(16 * s + i < rows_valid ? 16 * s + i : 0) * lda + wave * kw + 4 * kq;
+  const float* wp = W + (long)i * ldw + wave * kw + 4 * kq;
   for (int c0 = 0; c0 < nch; c0 += CH) {
     float4 a[RS][CH], b[NG][CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int cc = (c0 + c < nch) ? c0 + c : c0;            // past the end: repeat a valid chunk, skipped below
 #pragma unroll
-      for (int s = 0; s < RS; ++s) a[s][c] = *reinterpret_cast<const float4*>(ap[s] + 4 * cc);
+      for (int s = 0; s < RS; ++s) a[s][c] = *reinterpret_cast<const float4*>(ap[s] + 16 * cc);
 #pragma unroll
-      for (int g = 0; g < NG; ++g) b[g][c] = *reinterpret_cast<const float4*>(wp + (long)g * gstride * ldw + 4 * cc);
+      for (int g = 0; g < NG; ++g) b[g][c] = *reinterpret_cast<const float4*>(wp + (long)g * gstride * ldw + 16 * cc);
     }
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(256) void gru_bwd_step(GruArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b0 = blockIdx.x * 16 * RS, u0 = blockIdx.y * 16;
   const int H = a.H, t = a.t;
-  const bool last = t == a.T - 1;
+  const bool last = t == a.T - 1 && !a.continues;
   const int i = tid >> 4, j = tid & 15, u = u0 + j;
   bool live[RS];
   long row[RS], bb[RS];
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(256) void gru_bwd_step(GruArgs a) {
   for (int s = 0; s < RS; ++s) acc[s][0] = floatx4{0.f, 0.f, 0.f, 0.f};
   if (!last) {
     const float* dgh_next = a.dgh + ((long)b0 * a.sb + (long)(t + 1) * a.st) * 3 * H;
-    tile_product<1, 6>(dgh_next, (long)a.sb * 3 * H, a.B - b0, a.w + (long)u0 * 3 * H, 3 * H, 0, 3 * H, wave, lane, acc);
+    tile_product<1, 12>(dgh_next, (long)a.sb * 3 * H, a.B - b0, a.w + (long)u0 * 3 * H, 3 * H, 0, 3 * H, wave, lane, acc);
   }
   float back[RS][1];
   reduce_tiles<1>(acc, red, wave, lane, tid, back);
@@ -248,15 +252,18 @@ extern "C" int tvae_gru_fwd(const float* gi, const float* w_hh, const float* b_h
 
 extern "C" int tvae_gru_bwd(const float* dhseq, const float* dh_last, const float* hseq, const float* gates, const float* h0,
                             const float* w_hh_t, float* dgi, float* dgh, float* carry, int T, int B, int H, int time_major,
-                            void* stream) {
+                            int continues, void* stream) {
   TVAE_CHECK(hseq && gates && w_hh_t && dgi && dgh && carry, TVAE_E_NULL, "tvae_gru_bwd: null pointer");
-  TVAE_CHECK(dhseq || dh_last, TVAE_E_NULL, "tvae_gru_bwd: neither dhseq nor dh_last given");
+  TVAE_CHECK(dhseq || dh_last || continues, TVAE_E_NULL, "tvae_gru_bwd: neither dhseq nor dh_last given");
+  TVAE_CHECK(!continues || (time_major && !dh_last), TVAE_E_SHAPE,
+             "tvae_gru_bwd: a call that continues a later one needs time-major buffers (the next step's rows follow this call's) and no dh_last");
   if (int e = check_gru("tvae_gru_bwd", T, B, H, time_major)) return e;
   TVAE_CHECK(aligned16(w_hh_t) && aligned16(dgh), TVAE_E_SHAPE, "tvae_gru_bwd: operands must be 16-byte aligned");
   GruArgs a = {};
   a.w = w_hh_t; a.h0 = h0; a.hseq = const_cast<float*>(hseq); a.gates = const_cast<float*>(gates);
   a.dhseq = dhseq; a.dh_last = dh_last; a.dgi = dgi; a.dgh = dgh; a.carry = carry;
   a.T = T; a.B = B; a.H = H; a.sb = time_major ? 1 : T; a.st = time_major ? B : 1;
+  a.continues = continues;
   const dim3 grid(cdiv(B, 16 * RS), H / 16);
   for (int t = T - 1; t >= 0; --t) {
     a.t = t;

@@ -1016,14 +1016,43 @@ def _dropped(x2, drop):
     return out
 
 
+_gru_side = {}
+
+
+def _gru_streams(device, n):
+    "side streams of the layer pipeline, one per layer, kept per device"
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    have = _gru_side.setdefault(key, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device=device))
+    return have[:n]
+
+
+def _chunk_drop(drop, c):
+    "the dropout site of time chunk c of an inter-layer mask: chunks index their elements locally, so each gets its own stream"
+    return None if drop is None else Drop(drop.p, drop.site ^ ((c + 1) << 10), drop.rng)
+
+
+def _gru_chunks(T):
+    ch = int(os.environ.get("TVAE_GRU_CHUNK", "16"))
+    if ch <= 0 or ch >= T:
+        return [(0, T)]
+    return [(t0, min(T, t0 + ch)) for t0 in range(0, T, ch)]
+
+
 class GRUStackFn(torch.autograd.Function):
     """torch.nn.GRU(num_layers=N, dropout=p) on a (B, T, I) input from h0 = 0 (reference transvae/rnn_models.py:241, 301,
     333, 378): returns (output of the top layer (B, T, H), final state of the top layer (B, H)).
 
-    Per layer: the input projections of ALL time steps are one GEMM, the recurrence is tvae_gru_fwd (one fused launch per
-    time step), the inter-layer dropout is a mask regenerated in the backward pass.  Inside, sequences are time-major
-    (T, B, .) with a leading block of B zero rows (h_{-1}): the rows of h_{t-1} then sit exactly B rows before those of
-    h_t, which makes the recurrent weight gradient ONE product dgh^T [0; h_0 .. h_{T-2}] over all steps."""
+    Per layer: the input projections are GEMMs over many time steps at once, the recurrence is tvae_gru_fwd (one fused
+    launch per time step), the inter-layer dropout is a mask regenerated in the backward pass.  Inside, sequences are
+    time-major (T, B, .) with a leading block of B zero rows (h_{-1}): the rows of h_{t-1} then sit exactly B rows before
+    those of h_t, which makes the recurrent weight gradient ONE product dgh^T [0; h_0 .. h_{T-2}] over all steps.
+
+    A step launch is latency-bound (7 us forward, 13 us backward whatever the arithmetic in it), so a stack of N layers is
+    run as a PIPELINE over chunks of 16 time steps: layer l works on chunk c on its own HIP stream while layer l-1 is at
+    chunk c+1 (events hand the chunks over), which shortens the chain of dependent launches from N*T to T + 16 (N-1); the
+    backward pass does the same from the top layer and the last chunk down.  TVAE_GRU_CHUNK=0 runs layer after layer."""
 
     @staticmethod
     def forward(ctx, x, drops, *params):
@@ -1031,53 +1060,126 @@ class GRUStackFn(torch.autograd.Function):
         n_layers = len(params) // 4
         H = params[1].shape[1]
         _chk(x, "x")
-        cur = x.transpose(0, 1).contiguous().view(T * B, I)
+        dev = x.device
         need_grad = any(ctx.needs_input_grad)          # False under torch.no_grad(): nothing is kept for a backward pass
-        saved = []
-        for l in range(n_layers):
+        chunks = _gru_chunks(T) if n_layers > 1 else [(0, T)]
+        main = torch.cuda.current_stream()
+        x_tm = x.transpose(0, 1).contiguous().view(T * B, I)
+        f32 = dict(device=dev, dtype=torch.float32)
+        hbufs, gates, gis, xins = [], [], [], []
+        for l in range(n_layers):                      # every buffer is allocated on the caller's stream, before the pipeline
+            hb = torch.empty(((T + 1) * B, H), **f32)
+            hb[:B].zero_()
+            hbufs.append(hb)
+            gates.append(torch.empty((T * B, 4 * H), **f32) if need_grad else None)
+            gis.append(torch.empty((T * B, 3 * H), **f32))
+            if l == 0:
+                xins.append(x_tm)
+            elif drops[l - 1] is not None:
+                xins.append(torch.empty((T * B, H), **f32))
+            else:
+                xins.append(hbufs[l - 1][B:])
+        linear_fwd(x_tm, params[0], params[2], out=gis[0])
+        streams = _gru_streams(dev, n_layers) if len(chunks) > 1 else [main] * n_layers
+        done = [[None] * len(chunks) for _ in range(n_layers)]
+        for st in set(streams):
+            if st is not main:
+                st.wait_stream(main)
+        # launches are ENQUEUED in wavefront order (chunk c of layer l next to chunk c+1 of layer l-1): the host issues a
+        # launch about as fast as the GPU retires one, so work enqueued layer after layer would also run layer after layer
+        order = sorted(((l, c) for l in range(n_layers) for c in range(len(chunks))), key=lambda lc: (lc[0] + lc[1], lc[0]))
+        for l, c in order:
             w_ih, w_hh, b_ih, b_hh = params[4 * l:4 * l + 4]
-            xin = _dropped(cur, drops[l - 1]) if l > 0 else cur
-            gi = linear_fwd(xin, w_ih, b_ih)
-            hbuf = torch.empty(((T + 1) * B, H), device=x.device, dtype=torch.float32)
-            hbuf[:B].zero_()
-            hseq = hbuf[B:]
-            gates = torch.empty((T * B, 4 * H), device=x.device, dtype=torch.float32) if need_grad else None
-            call("tvae_gru_fwd", _p(gi), _p(w_hh), _p(b_hh), None, _p(hseq), _p(gates), T, B, H, 1, _stream())
-            if need_grad:
-                saved += [xin, hbuf, gates]
-            cur = hseq
-        out = cur.view(T, B, H).transpose(0, 1).contiguous()
-        h_last = cur.view(T, B, H)[T - 1].clone()
-        ctx.save_for_backward(*saved)
-        ctx.P, ctx.drops, ctx.dims = params, drops, (B, T, I, H, n_layers)
+            st = streams[l]
+            t0, t1 = chunks[c]
+            rows = slice(t0 * B, t1 * B)
+            with torch.cuda.stream(st):
+                if l > 0:
+                    if st is not main:
+                        st.wait_event(done[l - 1][c])
+                    if drops[l - 1] is not None:
+                        r, s_, p = _drop_args(_chunk_drop(drops[l - 1], c))
+                        src = hbufs[l - 1][B:][rows]
+                        call("tvae_residual_dropout", _p(src), None, _p(xins[l][rows]), src.shape[0], H, 0, 0, r, s_, p,
+                             _stream())
+                    linear_fwd(xins[l][rows], w_ih, b_ih, out=gis[l][rows])
+                call("tvae_gru_fwd", _p(gis[l][rows]), _p(w_hh), _p(b_hh), _p(hbufs[l][t0 * B:]),
+                     _p(hbufs[l][(t0 + 1) * B:]), _p(None if gates[l] is None else gates[l][rows]), t1 - t0, B, H, 1,
+                     _stream())
+                if st is not main:
+                    done[l][c] = st.record_event()
+        for st in streams:
+            if st is not main:
+                main.wait_stream(st)
+        top = hbufs[-1][B:]
+        out = top.view(T, B, H).transpose(0, 1).contiguous()
+        h_last = top.view(T, B, H)[T - 1].clone()
+        if need_grad:
+            saved = []
+            for l in range(n_layers):
+                saved += [xins[l], hbufs[l], gates[l]]
+            ctx.save_for_backward(*saved)
+        ctx.P, ctx.drops, ctx.dims, ctx.chunks = params, drops, (B, T, I, H, n_layers), chunks
         _note_use(*params)
         return out, h_last
 
     @staticmethod
     def backward(ctx, dout, dh_last):
         B, T, I, H, n_layers = ctx.dims
-        saved, params = ctx.saved_tensors, ctx.P
+        saved, params, chunks = ctx.saved_tensors, ctx.P, ctx.chunks
         dev = saved[0].device
-        d = None if dout is None else dout.transpose(0, 1).contiguous().view(T * B, H)
+        f32 = dict(device=dev, dtype=torch.float32)
+        main = torch.cuda.current_stream()
+        top = n_layers - 1
+        d = [None] * n_layers                          # gradient arriving at every h_t of layer l
+        d[top] = None if dout is None else dout.transpose(0, 1).contiguous().view(T * B, H)
         dl = None if dh_last is None else _c(dh_last)
-        grads = [None] * (4 * n_layers)
-        for l in range(n_layers - 1, -1, -1):
-            w_ih, w_hh, b_ih, b_hh = params[4 * l:4 * l + 4]
+        for l in range(top):
+            d[l] = torch.empty((T * B, H), **f32)
+        dgi = [torch.empty((T * B, 3 * H), **f32) for _ in range(n_layers)]
+        dgh = [torch.empty((T * B, 3 * H), **f32) for _ in range(n_layers)]
+        carry = [torch.empty((B, H), **f32) for _ in range(n_layers)]
+        w_hh_t = [params[4 * l + 1].detach().t().contiguous() for l in range(n_layers)]
+        streams = _gru_streams(dev, n_layers) if len(chunks) > 1 else [main] * n_layers
+        ready = [[None] * len(chunks) for _ in range(n_layers)]
+        for st in set(streams):
+            if st is not main:
+                st.wait_stream(main)
+        nc = len(chunks)
+        order = sorted(((l, c) for l in range(n_layers) for c in range(nc)), key=lambda lc: ((top - lc[0]) + (nc - 1 - lc[1]), -lc[0]))
+        for l, c in order:                             # wavefront from the top layer's last chunk down
+            w_ih = params[4 * l]
             xin, hbuf, gates = saved[3 * l:3 * l + 3]
-            dgi = torch.empty((T * B, 3 * H), device=dev, dtype=torch.float32)
-            dgh = torch.empty((T * B, 3 * H), device=dev, dtype=torch.float32)
-            carry = torch.empty((B, H), device=dev, dtype=torch.float32)
-            w_hh_t = w_hh.detach().t().contiguous()
-            call("tvae_gru_bwd", _p(d), _p(dl), _p(hbuf[B:]), _p(gates), None, _p(w_hh_t), _p(dgi), _p(dgh), _p(carry),
-                 T, B, H, 1, _stream())
-            dl = None
-            grads[4 * l], grads[4 * l + 2] = linear_wgrad(dgi, xin, W=w_ih, b=b_ih)
-            grads[4 * l + 1], grads[4 * l + 3] = linear_wgrad(dgh, hbuf[:T * B], W=w_hh, b=b_hh)
-            if l > 0 or ctx.needs_input_grad[0]:
-                d = linear_dgrad(dgi, w_ih)
+            st = streams[l]
+            t0, t1 = chunks[c]
+            rows = slice(t0 * B, t1 * B)
+            with torch.cuda.stream(st):
+                if l < top and st is not main:
+                    st.wait_event(ready[l + 1][c])
+                final = t1 == T
+                call("tvae_gru_bwd", _p(None if d[l] is None else d[l][rows]), _p(dl if (l == top and final) else None),
+                     _p(hbuf[(t0 + 1) * B:]), _p(gates[rows]), _p(hbuf[t0 * B:]), _p(w_hh_t[l]), _p(dgi[l][rows]),
+                     _p(dgh[l][rows]), _p(carry[l]), t1 - t0, B, H, 1, 0 if final else 1, _stream())
                 if l > 0:
-                    d = _dropped(d, ctx.drops[l - 1])
-        dx = d.view(T, B, I).transpose(0, 1).contiguous() if ctx.needs_input_grad[0] else None
+                    linear_dgrad(dgi[l][rows], w_ih, out=d[l - 1][rows])
+                    if ctx.drops[l - 1] is not None:
+                        r, s_, p = _drop_args(_chunk_drop(ctx.drops[l - 1], c))
+                        tgt = d[l - 1][rows]
+                        call("tvae_residual_dropout", _p(tgt), None, _p(tgt), tgt.shape[0], H, 0, 0, r, s_, p, _stream())
+                    if st is not main:
+                        ready[l][c] = st.record_event()
+        for st in streams:
+            if st is not main:
+                main.wait_stream(st)
+        grads = [None] * (4 * n_layers)
+        for l in range(n_layers):
+            w_ih, w_hh, b_ih, b_hh = params[4 * l:4 * l + 4]
+            xin, hbuf, _ = saved[3 * l:3 * l + 3]
+            grads[4 * l], grads[4 * l + 2] = linear_wgrad(dgi[l], xin, W=w_ih, b=b_ih)
+            grads[4 * l + 1], grads[4 * l + 3] = linear_wgrad(dgh[l], hbuf[:T * B], W=w_hh, b=b_hh)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = linear_dgrad(dgi[0], params[0]).view(T, B, I).transpose(0, 1).contiguous()
         return (dx, None) + tuple(grads)
 
 

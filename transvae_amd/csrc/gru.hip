@@ -37,9 +37,9 @@ constexpr int RS = 2;                    // 16-row sub-tiles per workgroup: a st
 
 // partial[s][g][r] of this wave: rows 16 s + 4 * (lane / 16) + r, unit lane % 16, over the wave's quarter of K.
 // A rows are `lda` floats apart, rows of W `ldw`; NG accumulators per sub-tile use W rows u0 + g * gstride + j.
-// A step is bound by what a CU can pull in from L2 (measured ~26 GB/s per CU), so a workgroup covers 32 rows with one
-// read of its W rows (16 x 16 tiles moved 1.6x the bytes per CU), and every operand byte of a batch of CH float4 per row is
-// requested before the first MFMA of the batch is issued (one L2 round trip per batch, not one per float4).
+// A step is a chain of latencies around 1.25 us of MFMA time, so every operand byte of a batch of CH float4 per row is
+// requested before the first MFMA of the batch is issued (one memory round trip per batch, not one per float4), and a
+// workgroup covers 32 rows with one read of its W rows.
 template <int NG, int CH>
 __device__ inline void tile_product(const float* __restrict__ A, long lda, int rows_valid, const float* __restrict__ W, int ldw,
                                     int gstride, int K, int wave, int lane, floatx4 (&acc)[RS][NG]) {

@@ -10,15 +10,17 @@ import pandas as pd
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from scripts.parsers import attn_parser, require_transformer  # noqa: E402
+from scripts.parsers import attn_parser  # noqa: E402
 from transvae_amd.data import make_src_mask, make_std_mask, vae_data_gen  # noqa: E402
+from transvae_amd.rnn_models import RNNAttn  # noqa: E402
 from transvae_amd.trans_models import TransVAE  # noqa: E402
 
 
 @torch.no_grad()
 def calc_attention(args):
-    require_transformer(args)
-    vae = TransVAE(load_fn=args.model_ckpt)
+    if args.model not in ('transvae', 'rnnattn'):
+        raise SystemExit("scripts/attention.py: --model must be transvae or rnnattn (the RNN model has no attention)")
+    vae = (TransVAE if args.model == 'transvae' else RNNAttn)(load_fn=args.model_ckpt)
     frame = pd.read_csv(args.mols)
     mols = frame.sample(args.n_samples).to_numpy() if args.shuffle else frame.to_numpy()[:args.n_samples, :]
     data = vae_data_gen(mols, props=None, char_dict=vae.params['CHAR_DICT'])
@@ -32,6 +34,17 @@ def calc_attention(args):
     vae.model.eval()
     dev = next(vae.model.parameters()).device
     n = n_batches * args.batch_size
+    if args.model == 'rnnattn':
+        # the weights of RNNAttnEncoder's attention over the sequence, one (127, 127) map per molecule (reference :83-101)
+        attn = torch.zeros((n, 1, 1, 127, 127))
+        for j in range(n_batches):
+            for i in range(args.batch_chunks):
+                start = j * args.batch_size + i * chunk
+                src = torch.as_tensor(np.asarray(data[start:start + chunk]))[:, :-1].to(dev).long()
+                _, _, _, wts = vae.model.encoder(vae.model.src_embed(src), return_attn=True)
+                attn[start:start + chunk, 0, 0] = wts
+        np.save(save_path + '.npy', attn.numpy())
+        return
     self_attn = torch.empty((n, 4, 4, 127, 127))
     src_attn = torch.empty((n, 3, 4, 126, 127))
     self_attn.zero_()           # rows past batch_chunks*chunk of a batch stay zero (uninitialised in the reference)

@@ -1,6 +1,6 @@
 """Command-line flags of the TransVAE scripts (same names and defaults as the reference's
 scripts/parsers.py:36-122, so existing job files keep working) and the small loaders the scripts share.
-All three model families are built: `--model transvae | rnnattn | rnn`; the attention dump is the transformer's."""
+All three model families are built: `--model transvae | rnnattn | rnn` (the attention dump: transvae | rnnattn)."""
 import argparse
 import io
 import json
@@ -77,13 +77,6 @@ def vocab_parser():
         ('--vocab_name', _opt('custom_char_dict', str)), ('--weights_name', _opt('custom_char_weights', str)),
         ('--save_dir', _opt('data', str)),
     ])
-
-
-def require_transformer(args):
-    "scripts/attention.py: the weights it dumps are those of the transformer's attention layers"
-    if args.model != 'transvae':
-        raise SystemExit("the attention dump covers the transformer VAE (--model transvae); for '%s' use "
-                         "RNNAttnEncoder.forward(x, return_attn=True)" % args.model)
 
 
 def default_save_name(args):

@@ -277,3 +277,33 @@ def test_rnn_checkpoint_roundtrip_and_shell_calls(tmp_path):
         m, mu, lv = again.calc_mems(np.stack([smiles, np.zeros(4)], 1), log=False, save=False)
         assert m.shape == mu.shape == lv.shape == (4, 128)
     assert len(again.sample(3)) == 3
+
+
+def test_rnnattn_attention_weights_and_script(tmp_path):
+    "RNNAttnEncoder(return_attn=True) against the reference's weights; scripts/attention.py --model rnnattn writes them (reference scripts/attention.py:83-101)"
+    import os
+    import subprocess
+    import sys
+    g = load("rnn_attn_rnnattn256")
+    vae = build("rnnattn256", BATCH_SIZE=6, BATCH_CHUNKS=2)
+    vae.model.eval()
+    toks = torch.from_numpy(g["tokens"].astype(np.int64)).to(DEV)
+    with torch.no_grad():
+        _, mu, _, wts = vae.model.encoder(vae.model.src_embed(toks), return_attn=True)
+    assert rel_l2(wts, g["attn"]) < 1e-5 and rel_l2(mu.cpu(), g["mu"]) < 1e-5
+    assert float((wts.sum(-1) - 1).abs().max()) < 1e-5
+    # the script, end to end, on molecules written as SMILES (vocabulary of the checkpoint)
+    vae.current_state['model_state_dict'] = vae.model.state_dict()
+    vae.current_state['optimizer_state_dict'] = vae.optimizer.state_dict
+    ckpt = str(tmp_path / "ra.ckpt")
+    vae.save(vae.current_state, ckpt, use_name=False)
+    mols = tmp_path / "mols.txt"
+    mols.write_text("mol\n" + "\n".join(["CCO", "c1ccccc1", "CC(=O)O", "CCN", "CCCC", "C1CC1"]) + "\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "w")
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "attention.py"), "--model", "rnnattn", "--model_ckpt", ckpt,
+                        "--mols", str(mols), "--n_samples", "6", "--batch_size", "6", "--batch_chunks", "2", "--save_path", out],
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    w = np.load(out + ".npy")
+    assert w.shape == (6, 1, 1, 127, 127) and np.allclose(w.sum(-1), 1.0, atol=1e-5)

@@ -71,3 +71,12 @@ def test_rnn_greedy_decode_tokens(name):
     assert (ids.numpy() == want).all(axis=1).mean() >= 0.9
     assert (ids_c.numpy() == g["ids_cond"].astype(np.int64)).all(axis=1).mean() >= 0.8
     assert (ids_c[:, :2].numpy() == np.array([cd[str(t)] for t in g["cond"]])).all()
+
+
+def test_rnnattn_attention_weights():
+    g = load("rnn_attn_rnnattn256")
+    P = rnn_oracle_params("rnnattn256")
+    with torch.no_grad():
+        _, mu, _, w = R.encode(P, torch.from_numpy(g["tokens"].astype(np.int64)), eps=torch.zeros(6, 128))
+    np.testing.assert_allclose(w.numpy(), g["attn"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(mu.numpy(), g["mu"], rtol=1e-4, atol=2e-6)

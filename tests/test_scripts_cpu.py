@@ -42,10 +42,14 @@ def test_sample_and_attn_flags():
         assert getattr(a, k) == v, k
 
 
-def test_non_transformer_models_are_refused():
-    a = parsers.train_parser().parse_args(['--model', 'rnn', '--data_source', 'zinc'])
-    with pytest.raises(SystemExit):
-        parsers.require_transformer(a)
+def test_default_save_names_of_the_three_model_families():
+    "reference scripts/parsers.py:7-17: trans{d_ff/d_model}x-{d_model}_{source} | {model}-{d_model}_{source} | --save_name"
+    a = parsers.train_parser().parse_args(['--model', 'transvae', '--d_model', '256', '--d_feedforward', '1024', '--data_source', 'zinc'])
+    assert parsers.default_save_name(a) == 'trans4x-256_zinc'
+    a = parsers.train_parser().parse_args(['--model', 'rnnattn', '--d_model', '256', '--data_source', 'pubchem'])
+    assert parsers.default_save_name(a) == 'rnnattn-256_pubchem'
+    a = parsers.train_parser().parse_args(['--model', 'rnn', '--data_source', 'zinc', '--save_name', 'mine'])
+    assert parsers.default_save_name(a) == 'mine'
 
 
 def test_vocab_loader_reads_plain_pickles_only(tmp_path):

@@ -251,6 +251,19 @@ def golden_adam(rm, loss_mod, name):
         print("   %-32s reference fp32 vs fp64 after 3 steps: median %.2e max %.2e (lr 1e-4)" % (k, np.median(dd), dd.max()))
 
 
+def golden_attn(rm, name="rnnattn256", n=6):
+    "attention weights of RNNAttnEncoder (rnn_models.py:246, return_attn=True), as scripts/attention.py dumps them"
+    from transvae_amd import synth
+    vae = build(rm, name)
+    vae.model.eval()
+    toks = synth.synth_tokens(n, seed=77, lengths=[1, 126, 35, 60, 22, 90][:n])
+    with torch.no_grad():
+        _, mu, _, wts = vae.model.encoder(vae.model.src_embed(toks.long()), return_attn=True)
+    np.savez_compressed(os.path.join(OUT, "rnn_attn_%s.npz" % name), tokens=toks.numpy().astype(np.int8),
+                        attn=wts.numpy().astype(np.float32), mu=mu.numpy())
+    print("attn", name, tuple(wts.shape), float(wts.sum(-1).mean()))
+
+
 def golden_decode(rm, name, n=16):
     vae = build(rm, name)
     vae.use_gpu = False
@@ -275,6 +288,10 @@ def main():
             golden_step(rm, loss_mod, name)
         if only in ("", "decode"):
             golden_decode(rm, name)
+    if only in ("", "attn"):
+        golden_attn(rm)
+    if only not in ("", "adam"):
+        return
     golden_adam(rm, loss_mod, "rnnattn256")
     golden_adam(rm, loss_mod, "rnn128_pp")
 

@@ -113,7 +113,9 @@ __device__ inline void stage_offsets(unsigned (&off)[BK / 8], int ld, int row0, 
   for (int j = 0; j < BK / 8; ++j) {
     int row, k;
     stage_pos<BK, KM>(tid + 256 * j, row, k);
-    const int gr = min(row0 + row, KM ? nrows - 4 : nrows - 1);      // KM: a float4 spans rows gr .. gr + 3 (nrows % 4 == 0)
+    // relative to the tile's first row (the caller's base pointer carries row0): operands of any size, offsets < 2^32 as long
+    // as 128 rows (or 32 k-rows of a k-major operand) span less than 4 GiB
+    const int gr = min(row0 + row, KM ? nrows - 4 : nrows - 1) - row0;      // KM: a float4 spans rows gr .. gr + 3 (nrows % 4 == 0)
     off[j] = 4u * (KM ? (unsigned)k * (unsigned)ld + (unsigned)gr : (unsigned)gr * (unsigned)ld + (unsigned)k);
   }
 }
@@ -258,8 +260,8 @@ void gemm_kernel(GemmArgs g) {
   auto load_step = [&](int k0, bool checked) {
     if constexpr (FAST) {
       if (!checked) {
-        stage_load_fast<BK>(sa, g.A + (A_KM ? (size_t)k0 * g.lda : (size_t)k0), offA);
-        stage_load_fast<BK>(sb, g.B + (B_KM ? (size_t)k0 * g.ldb : (size_t)k0), offB);
+        stage_load_fast<BK>(sa, g.A + (A_KM ? (size_t)k0 * g.lda + m0 : (size_t)m0 * g.lda + k0), offA);
+        stage_load_fast<BK>(sb, g.B + (B_KM ? (size_t)k0 * g.ldb + n0 : (size_t)n0 * g.ldb + k0), offB);
         return;
       }
     }
@@ -504,9 +506,10 @@ static int gemm_impl(const float* A, int lda, const float* B, int ldb, float* C,
     g.flags |= FLAG_VEC_EPILOGUE;
   TVAE_CHECK(!a_rowsum || a_km, TVAE_E_SHAPE, "tvae_gemm: a_rowsum needs a k-major A (wgrad form)");
   {
-    // fast staging needs every byte offset inside an operand below 4 GiB (32-bit per-thread offsets) and, for the clamped
-    // rows, at least one whole row group to clamp to
-    const double extA = 4.0 * (a_km ? (double)32 * lda + M : (double)M * lda + 32), extB = 4.0 * (b_km ? (double)32 * ldb + N : (double)N * ldb + 32);
+    // fast staging needs the byte offsets inside ONE TILE's rows below 4 GiB (32-bit per-thread offsets relative to the
+    // tile's first row: the operand itself may be of any size -- the 8.3 M-row memory expansion of a 65536-latent decode
+    // slab is 8.5 GB) and, for the clamped rows, at least one whole row group to clamp to
+    const double extA = 4.0 * (a_km ? (double)32 * lda + 128 : (double)128 * lda + 32), extB = 4.0 * (b_km ? (double)32 * ldb + 128 : (double)128 * ldb + 32);
     if (aligned && extA < 4.0e9 && extB < 4.0e9 && M >= 4 && N >= 4) g.flags |= FLAG_FAST_STAGE;
   }
   const bool bf16 = dtype == TVAE_BF16;

@@ -72,6 +72,30 @@ def test_batch500_one_pass_equals_the_chunk_loop_4x256():
            ["%-58s %10.2e" % (k, e) for k, e in sorted(errs.items(), key=lambda kv: -kv[1])])
 
 
+def test_batch500_one_pass_equals_the_chunk_loop_rnnattn256():
+    "the same property for the recurrent family at full size: rnnattn-256, batch 500 = 5 x 100 (GRU layer pipeline on)"
+    from test_rnn_gpu import build as build_rnn
+    data = _batch(500, seed=101)
+    eps = torch.randn(500, 128, generator=torch.Generator().manual_seed(12)).cuda()
+    grads, tables = [], []
+    for fuse in (True, False):
+        vae = build_rnn("rnnattn256", BATCH_SIZE=500, BATCH_CHUNKS=5, FUSE_CHUNKS=fuse)
+        vae.model.eval()
+        vae.optimizer.optimizer.fuse_zero_grad = False
+        tables.append(vae.train_step(data, 0.02, eps=eps).cpu().numpy())
+        grads.append({k: p.grad.detach().cpu().numpy().copy() for k, p in vae.model.named_parameters() if p.grad is not None})
+        del vae
+    assert tables[0].shape == (5, 5) and float(np.abs(tables[0][:, 2]).max()) == 0.0        # no length term
+    np.testing.assert_allclose(tables[0], tables[1], rtol=2e-6, atol=1e-7)
+    errs = {k: rel_l2(grads[0][k], grads[1][k]) for k in grads[0] if np.linalg.norm(grads[1][k]) > 0}
+    _report_and_check("one pass vs chunk loop, rnnattn-256, batch 500", errs)
+    from helpers import record
+    record("fullsize_batch500_fused_vs_loop_rnnattn256",
+           ["# rnnattn-256: one pass over 500 with per-chunk normalisation vs the literal loop over 5 chunks of 100",
+            "loss table max rel diff %.2e" % float(np.abs(tables[0] - tables[1]).max() / np.abs(tables[1]).max())] +
+           ["%-58s %10.2e" % (k, e) for k, e in sorted(errs.items(), key=lambda kv: -kv[1])])
+
+
 def test_full_chunk_of_100_gate_safe_molecules_at_the_golden_bar_4x256():
     """A FULL chunk (100 SMILES-shaped molecules, trans4x-256) against the float64 oracle at the bar of the golden
     test (tests/test_model_gpu.py: every loss term 1e-5; every gradient tensor within max(2e-5, 10 x the error of a

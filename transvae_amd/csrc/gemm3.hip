@@ -190,10 +190,11 @@ void gemm3_kernel(GemmArgs g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, hh = lane >> 5;
   const int ntn = (g.N + BN - 1) / BN;
-  const int wgid = xcd_tile_id();
+  int wgid;
+  if (!tile_and_split(g, wgid)) return;
   const int tile_n = wgid % ntn, tile_m = wgid / ntn;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int kbeg = blockIdx.z * g.k_per_split;
+  const int kbeg = g.split * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
   const int nkt = (kend - kbeg + BK3 - 1) / BK3;
 
@@ -422,7 +423,7 @@ extern "C" int tvae_split3(const float* w, int ldw, uint16_t* out_n, uint16_t* o
 // called by tvae_gemm (gemm.hip) once shapes and flags are validated and `g` is filled in
 void tvae_gemm3_launch(const void* gp, int tiles, int splits, bool a_km, bool b_km, bool drop, bool b_split, hipStream_t s) {
   const GemmArgs& g = *reinterpret_cast<const GemmArgs*>(gp);
-  dim3 grid(tiles, 1, splits);
+  dim3 grid(tiles, 1, splits > 1 ? cdiv(splits, 8) * 8 : 1);   // padded: see tile_and_split
   if (b_split) {                       // B is pre-split, k-contiguous by construction
     if (!a_km) launch3<false, false, true>(g, grid, s, drop);
     else launch3<true, false, true>(g, grid, s, false);

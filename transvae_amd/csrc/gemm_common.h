@@ -17,6 +17,8 @@ struct GemmArgs {
   int k_per_split;
   float* a_rowsum;   // A_KMAJOR only: a_rowsum[m] += sum_k A(m,k) (bias gradient fused into wgrad)
   long sA, sB, sC, sR;   // tvae_gemm_batched: element strides between the matrices of consecutive batch entries (blockIdx.y)
+  int n_splits;          // split-K: slabs of K (the grid's z extent is this rounded up to a multiple of 8, see tile_and_split)
+  int split;             // written by the kernel: the slab this workgroup sums
 };
 
 
@@ -27,6 +29,18 @@ struct GemmArgs {
 __device__ inline int xcd_tile_id() {
   const int nwg = gridDim.x, id = blockIdx.x, q = nwg >> 3, rr = nwg & 7, xcd = id & 7;
   return (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (id >> 3);
+}
+
+// Split-K placement (grid = tiles x 1 x splits rounded up to 8).  With blockIdx.z as the slab, an XCD saw ONE row panel of
+// tiles for every slab, so each slab of the operand that all row panels share was fetched by all 8 L2s (PMC: 830 MB per
+// launch of the 63500-token dW[1024,256] against 325 MB of operands).  Dealt this way, the tiles of one slab are consecutive
+// workgroups of ONE XCD and both operand slabs enter one L2 once.  Returns false for the padding workgroups.
+__device__ inline bool tile_and_split(GemmArgs& g, int& wgid) {
+  if (gridDim.z == 1) { wgid = xcd_tile_id(); g.split = 0; return true; }
+  const int f = blockIdx.z * gridDim.x + blockIdx.x, j = f >> 3;
+  wgid = j % (int)gridDim.x;
+  g.split = (j / (int)gridDim.x) * 8 + (f & 7);
+  return g.split < g.n_splits;
 }
 
 // Epilogue of a 128x128 tile held as 2x2 MFMA 32x32 accumulators per wave (4 waves as 2x2):
@@ -45,7 +59,7 @@ __device__ inline void gemm_epilogue(const GemmArgs& g, floatx16 (&acc)[2][2], f
   const bool relu = g.flags & TVAE_GEMM_RELU, accum = g.flags & TVAE_GEMM_ACCUM;
   const bool splitk = g.flags & TVAE_GEMM_SPLITK, relumask = g.flags & 64;
   DropCfg de = drop_cfg((g.flags & TVAE_GEMM_A_DROPMASK) ? nullptr : g.rng, g.site, g.p);
-  const bool lead = (blockIdx.z == 0);
+  const bool lead = (g.split == 0);
   if (g.flags & FLAG_VEC_EPILOGUE) {
     // Row-per-lane accumulator stores are issue-bound (64 dword stores per lane).  Turn the wave's
     // 64x64 tile through its own LDS slab instead and leave as 16 float4 per lane: 16 lanes cover

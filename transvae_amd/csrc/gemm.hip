@@ -448,12 +448,14 @@ int forced_depth() {   // TVAE_GEMM_BK (16 | 32) overrides the choice below; rea
   return (forced == 16 || forced == 32) ? forced : 0;
 }
 
-// BK = 16 runs three workgroups per CU and is a few percent faster when the grid fills whole
+// BK = 16 runs four workgroups per CU and is a few percent faster when the grid fills whole
 // rounds of them; a grid that leaves the last round mostly empty is better off with BK = 32.
-int tile_depth(bool bf16, int tiles, bool splitk) {
+int tile_depth(bool bf16, int tiles, bool splitk, bool drop) {
   if (int f = forced_depth()) return f;
   if (bf16) return 32;
-  if (splitk) return tiles <= 4 ? 32 : 16;   // few tiles = many slabs: half as many atomic epilogues (dW[256,256]: 115 -> 104 us)
+  // split-K: half as many slabs (atomic epilogues) for the same K -- 276 vs 283 us on dW[1024,256], 90 vs 105 on dW[256,256];
+  // the form that regenerates a dropout mask while staging is the other way round (304 vs 308, 167 vs 172)
+  if (splitk) return drop ? 16 : 32;
   auto eff = [](int t, int slots) { return (double)t / (double)(cdiv(t, slots) * slots); };
   return eff(tiles, SLOTS16) * 1.03 >= eff(tiles, SLOTS32) ? 16 : 32;
 }
@@ -544,7 +546,7 @@ static int gemm_impl(const float* A, int lda, const float* B, int ldb, float* C,
     TVAE_LAUNCH_CHECK("tvae_gemm");
     return TVAE_OK;
   }
-  const int BK = x3 ? 32 : tile_depth(bf16, tiles, flags & TVAE_GEMM_SPLITK);
+  const int BK = x3 ? 32 : tile_depth(bf16, tiles, flags & TVAE_GEMM_SPLITK, drop);
   int splits = 1;
   if (flags & TVAE_GEMM_SPLITK) {
     // one full round of resident workgroups, each with at least 256 of K: more splits only add

@@ -219,7 +219,7 @@ void gemm_kernel(GemmArgs g) {
   const int r = lane & 31, hh = lane >> 5;
   const int ntn = (g.N + BN - 1) / BN;
   int wgid;
-  if (!tile_and_split(g, wgid)) return;
+  tile_and_split(g, wgid);
   const int tile_n = wgid % ntn, tile_m = wgid / ntn;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int kbeg = g.split * g.k_per_split;
@@ -500,7 +500,7 @@ static int gemm_impl(const float* A, int lda, const float* B, int ldb, float* C,
   if (batch > 1 && (sA % 4 || sB % 4)) aligned = false;
   GemmArgs g;
   g.sA = sA; g.sB = sB; g.sC = sC; g.sR = sR;
-  g.n_splits = 1; g.split = 0;
+  g.split = 0;
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.res = residual;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.M = M; g.N = N; g.K = K;
   g.alpha = alpha; g.flags = flags; g.rng = rng; g.site = site; g.p = p_drop;
@@ -554,22 +554,20 @@ static int gemm_impl(const float* A, int lda, const float* B, int ldb, float* C,
     int ktiles = cdiv(K, 32);
     splits = (BK == 16 ? SLOTS16 : SLOTS32) / tiles;
     if (splits > ktiles / 8) splits = ktiles / 8;
-    if (splits >= 8) splits &= ~7;   // whole groups of 8 slabs (tile_and_split deals one per XCD): the padded grid stays one round
     if (splits < 1) splits = 1;
-    if (splits > 65528) splits = 65528;
+    if (splits > 65535) splits = 65535;
     g.k_per_split = cdiv(ktiles, splits) * 32;
     splits = cdiv(K, g.k_per_split);
   } else {
     g.k_per_split = cdiv(K, 32) * 32;
   }
-  g.n_splits = splits;
   hipStream_t s = (hipStream_t)stream;
   if (x3) {
     tvae_gemm3_launch(&g, tiles, splits, a_km, b_km, drop, b_split, s);
     TVAE_LAUNCH_CHECK("tvae_gemm");
     return TVAE_OK;
   }
-  dim3 grid(tiles, batch, splits > 1 ? cdiv(splits, 8) * 8 : 1);   // padded: see tile_and_split
+  dim3 grid(tiles, batch, splits);
   if (BK == 16) launch0<16>(g, grid, s, a_km, b_km, aligned, bf16, drop);
   else launch0<32>(g, grid, s, a_km, b_km, aligned, bf16, drop);
   TVAE_LAUNCH_CHECK("tvae_gemm");

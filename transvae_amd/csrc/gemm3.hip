@@ -191,7 +191,7 @@ void gemm3_kernel(GemmArgs g) {
   const int r = lane & 31, hh = lane >> 5;
   const int ntn = (g.N + BN - 1) / BN;
   int wgid;
-  if (!tile_and_split(g, wgid)) return;
+  tile_and_split(g, wgid);
   const int tile_n = wgid % ntn, tile_m = wgid / ntn;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int kbeg = g.split * g.k_per_split;
@@ -423,7 +423,7 @@ extern "C" int tvae_split3(const float* w, int ldw, uint16_t* out_n, uint16_t* o
 // called by tvae_gemm (gemm.hip) once shapes and flags are validated and `g` is filled in
 void tvae_gemm3_launch(const void* gp, int tiles, int splits, bool a_km, bool b_km, bool drop, bool b_split, hipStream_t s) {
   const GemmArgs& g = *reinterpret_cast<const GemmArgs*>(gp);
-  dim3 grid(tiles, 1, splits > 1 ? cdiv(splits, 8) * 8 : 1);   // padded: see tile_and_split
+  dim3 grid(tiles, 1, splits);
   if (b_split) {                       // B is pre-split, k-contiguous by construction
     if (!a_km) launch3<false, false, true>(g, grid, s, drop);
     else launch3<true, false, true>(g, grid, s, false);

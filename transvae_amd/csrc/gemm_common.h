@@ -18,30 +18,28 @@ struct GemmArgs {
   int k_per_split;
   float* a_rowsum;   // A_KMAJOR only: a_rowsum[m] += sum_k A(m,k) (bias gradient fused into wgrad)
   long sA, sB, sC, sR;   // tvae_gemm_batched: element strides between the matrices of consecutive batch entries (blockIdx.y)
-  int n_splits;          // split-K: slabs of K (the grid's z extent is this rounded up to a multiple of 8, see tile_and_split)
   int split;             // written by the kernel: the slab this workgroup sums
 };
 
 
-// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (id % 8 shares an L2),
-// so give each XCD a CONTIGUOUS run of tiles -- the column tiles that re-read one A row panel then
-// hit the same L2 instead of fetching the panel once per XCD.  (Bijective for any grid size;
-// placement is a speed matter only.)
-__device__ inline int xcd_tile_id() {
-  const int nwg = gridDim.x, id = blockIdx.x, q = nwg >> 3, rr = nwg & 7, xcd = id & 7;
+// XCD-aware work order: workgroups are dealt round-robin over the 8 XCDs (flat id % 8 shares an L2), so give each XCD a
+// CONTIGUOUS run of the work list -- the column tiles that re-read one A row panel then hit the same L2 instead of
+// fetching the panel once per XCD.  (Bijective for any count; placement is a speed matter only.)
+__device__ inline int xcd_order(int nwg, int id) {
+  const int q = nwg >> 3, rr = nwg & 7, xcd = id & 7;
   return (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (id >> 3);
 }
+__device__ inline int xcd_tile_id() { return xcd_order(gridDim.x, blockIdx.x); }
 
-// Split-K placement (grid = tiles x 1 x splits rounded up to 8).  With blockIdx.z as the slab, an XCD saw ONE row panel of
-// tiles for every slab, so each slab of the operand that all row panels share was fetched by all 8 L2s (PMC: 830 MB per
-// launch of the 63500-token dW[1024,256] against 325 MB of operands).  Dealt this way, the tiles of one slab are consecutive
-// workgroups of ONE XCD and both operand slabs enter one L2 once.  Returns false for the padding workgroups.
-__device__ inline bool tile_and_split(GemmArgs& g, int& wgid) {
-  if (gridDim.z == 1) { wgid = xcd_tile_id(); g.split = 0; return true; }
-  const int f = blockIdx.z * gridDim.x + blockIdx.x, j = f >> 3;
-  wgid = j % (int)gridDim.x;
-  g.split = (j / (int)gridDim.x) * 8 + (f & 7);
-  return g.split < g.n_splits;
+// Split-K (grid = tiles x 1 x slabs): the work list is slab-major, so an XCD's run is whole slabs (and at most two partial
+// ones) with all their tiles, and both operand slabs enter one L2 once.  With blockIdx.z as the slab an XCD saw ONE row
+// panel of tiles for every slab, and each slab of the operand that all row panels share was fetched by all 8 L2s (PMC:
+// 830 MB per launch of the 63500-token dW[1024,256] against 325 MB of operands; now 329 MB).
+__device__ inline void tile_and_split(GemmArgs& g, int& wgid) {
+  if (gridDim.z == 1) { wgid = xcd_tile_id(); g.split = 0; return; }
+  const int nt = gridDim.x, w = xcd_order(nt * (int)gridDim.z, (int)blockIdx.z * nt + (int)blockIdx.x);
+  g.split = w / nt;
+  wgid = w - g.split * nt;
 }
 
 // Epilogue of a 128x128 tile held as 2x2 MFMA 32x32 accumulators per wave (4 waves as 2x2):

@@ -54,11 +54,14 @@ __device__ inline void tile_commit(const TileRegs<DK>& R, float* __restrict__ T,
   }
 }
 
+// A lane's half row into registers.  Unconditional: the callers clamp the row of a lane beyond the molecule to row 0 (such a
+// lane computes a copy of row 0 and stores nothing).  A load under `if (valid)` is a branch whose join makes the compiler
+// wait for the load right there -- in the middle of the prologue's load burst, one memory latency per call.
 template <int HALF>
-__device__ inline void load_row_half(float (&reg)[HALF], const float* __restrict__ rowp, bool valid) {
+__device__ inline void load_row_half(float (&reg)[HALF], const float* __restrict__ rowp) {
 #pragma unroll
   for (int s = 0; s < HALF; s += 4) {
-    float4 v = valid ? *reinterpret_cast<const float4*>(rowp + s) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 v = *reinterpret_cast<const float4*>(rowp + s);
     reg[s] = v.x; reg[s + 1] = v.y; reg[s + 2] = v.z; reg[s + 3] = v.w;
   }
 }
@@ -142,8 +145,13 @@ __device__ inline Live live_tiles(const uint32_t (&mw)[4]) {
 
 // key-mask words of molecule b into LDS (bit j of word t = key 32t+j unmasked and < Lk): wave 0 ballots
 __device__ inline void load_key_bits(uint32_t* key_bits, const AttnArgs& a, int b, int tid) {
+  // the byte is loaded by every thread from a clamped address (any readable byte when there is no mask): no branch around
+  // the load, see load_row_half
+  const int kc = min(tid & 127, a.Lk - 1);
+  const uint8_t* kp = a.key_mask ? a.key_mask + (size_t)b * a.Lk + kc : reinterpret_cast<const uint8_t*>(a.q);
+  const uint8_t kb = *kp;
   if (tid < 128) {
-    const bool m = (tid < a.Lk) && (a.key_mask ? a.key_mask[(size_t)b * a.Lk + tid] != 0 : true);
+    const bool m = (tid < a.Lk) && (a.key_mask ? kb != 0 : true);
     const unsigned long long bal = __ballot(m);
     if ((tid & 63) == 0) { key_bits[(tid >> 6) * 2] = (uint32_t)bal; key_bits[(tid >> 6) * 2 + 1] = (uint32_t)(bal >> 32); }
   }
@@ -175,7 +183,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     TileRegs<DK> rk, rv;
     tile_issue<DK>(rk, a.k + (size_t)b * a.Lk * a.ldk + head * DK, a.ldk, a.Lk, tid);
     tile_issue<DK>(rv, a.v + (size_t)b * a.Lk * a.ldv + head * DK, a.ldv, a.Lk, tid);
-    load_row_half<HALF>(qreg, a.q + ((size_t)b * a.Lq + qs) * a.ldq + head * DK + hh * HALF, qvalid);
+    load_row_half<HALF>(qreg, a.q + ((size_t)b * a.Lq + qs) * a.ldq + head * DK + hh * HALF);
     load_key_bits(key_bits, a, b, tid);
     tile_commit<DK>(rk, Ks, a.Lk, tid);
     tile_commit<DK>(rv, Vs, a.Lk, tid);
@@ -286,8 +294,9 @@ void attn_bwd_dq_kernel(AttnArgs a) {
   const int qs = qvalid ? qi : 0;
 
   const size_t prow = ((size_t)(b * a.h + head) * a.Lq + qi);
-  const float row_mx = qvalid ? a.lse_in[2 * prow] : 0.f;
-  const float row_ls = qvalid ? a.lse_in[2 * prow + 1] : 0.f;
+  const size_t prow_s = ((size_t)(b * a.h + head) * a.Lq + qs);   // clamped: a lane beyond Lq uses neither (nk = 0 below)
+  const float row_mx = a.lse_in[2 * prow_s];
+  const float row_ls = a.lse_in[2 * prow_s + 1];
   DropCfg dc = drop_cfg(a.rng, a.site, a.p);
   floatx16 pt[4], dpt[4];
   uint32_t mwt[4], kwt[4];
@@ -298,8 +307,8 @@ void attn_bwd_dq_kernel(AttnArgs a) {
       TileRegs<DK> rk, rv;
       tile_issue<DK>(rk, a.k + (size_t)b * a.Lk * a.ldk + head * DK, a.ldk, a.Lk, tid);
       tile_issue<DK>(rv, a.v + (size_t)b * a.Lk * a.ldv + head * DK, a.ldv, a.Lk, tid);
-      load_row_half<HALF>(qreg, a.q + ((size_t)b * a.Lq + qs) * a.ldq + head * DK + hh * HALF, qvalid);
-      load_row_half<HALF>(doreg, a.d_o + ((size_t)b * a.Lq + qs) * a.lddo + head * DK + hh * HALF, qvalid);
+      load_row_half<HALF>(qreg, a.q + ((size_t)b * a.Lq + qs) * a.ldq + head * DK + hh * HALF);
+      load_row_half<HALF>(doreg, a.d_o + ((size_t)b * a.Lq + qs) * a.lddo + head * DK + hh * HALF);
       load_key_bits(key_bits, a, b, tid);
       tile_commit<DK>(rk, Ks, a.Lk, tid);
       tile_commit<DK>(rv, Vs, a.Lk, tid);
@@ -397,28 +406,34 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
 
   DropCfg dc = drop_cfg(a.rng, a.site, a.p);
   float kreg[HALF], vreg[HALF];
+  TileRegs<DK> rq, rg;
   {
-    TileRegs<DK> rq, rg;
     tile_issue<DK>(rq, a.q + (size_t)b * a.Lq * a.ldq + head * DK, a.ldq, a.Lq, tid);
     tile_issue<DK>(rg, a.d_o + (size_t)b * a.Lq * a.lddo + head * DK, a.lddo, a.Lq, tid);
-    load_row_half<HALF>(kreg, a.k + ((size_t)b * a.Lk + ks) * a.ldk + head * DK + hh * HALF, kvalid);
-    load_row_half<HALF>(vreg, a.v + ((size_t)b * a.Lk + ks) * a.ldv + head * DK + hh * HALF, kvalid);
-    tile_commit<DK>(rq, Qs, a.Lq, tid);
-    tile_commit<DK>(rg, Gs, a.Lq, tid);
+    load_row_half<HALF>(kreg, a.k + ((size_t)b * a.Lk + ks) * a.ldk + head * DK + hh * HALF);
+    load_row_half<HALF>(vreg, a.v + ((size_t)b * a.Lk + ks) * a.ldv + head * DK + hh * HALF);
   }
+  // Row statistics, keep words and the key-mask byte: issued with the tiles, from clamped addresses and without branches
+  // (they used to follow the tiles as four load -> wait -> load chains: four more memory latencies in every prologue).
+  const int srow = min(tid & 127, a.Lq - 1);
+  const size_t prow = (size_t)(b * a.h + head) * a.Lq + srow;
+  const float st_mx = a.lse_in[2 * prow], st_inv = a.lse_in[2 * prow + 1], st_ds = a.dsum[prow];
+  const size_t rows_pad = ((size_t)a.B * a.h * a.Lq + 3) & ~(size_t)3;
+  const uint32_t* kwp = dc.on ? reinterpret_cast<const uint32_t*>(a.dsum) + rows_pad + 4 * prow
+                              : reinterpret_cast<const uint32_t*>(a.dsum);          // any readable 16 bytes
+  const uint4 kw = *reinterpret_cast<const uint4*>(kwp);
+  const uint8_t* kmp = a.key_mask ? a.key_mask + (size_t)b * a.Lk + ks : reinterpret_cast<const uint8_t*>(a.q);
+  const uint8_t kmb = *kmp;
+  tile_commit<DK>(rq, Qs, a.Lq, tid);
+  tile_commit<DK>(rg, Gs, a.Lq, tid);
   if (tid < 128) {
-    size_t prow = ((size_t)(b * a.h + head) * a.Lq + tid);
     const bool ok = tid < a.Lq;
-    stat_s[tid] = ok ? make_float4(a.lse_in[2 * prow], a.lse_in[2 * prow + 1], a.dsum[prow], 0.f)
-                     : make_float4(0.f, 0.f, 0.f, 0.f);
-    const size_t rows_pad = ((size_t)a.B * a.h * a.Lq + 3) & ~(size_t)3;
-    uint4 w = make_uint4(~0U, ~0U, ~0U, ~0U);
-    if (ok && dc.on) w = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(a.dsum) + rows_pad + 4 * prow);
-    *reinterpret_cast<uint4*>(&keep_s[tid][0]) = w;
+    stat_s[tid] = ok ? make_float4(st_mx, st_inv, st_ds, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<uint4*>(&keep_s[tid][0]) = (ok && dc.on) ? kw : make_uint4(~0U, ~0U, ~0U, ~0U);
   }
-  const bool kbit = kvalid && (a.key_mask ? a.key_mask[(size_t)b * a.Lk + key] != 0 : true);
+  const bool kbit = kvalid && (a.key_mask ? kmb != 0 : true);
   // a fully masked query row (row max == the fill value) spreads weight over masked keys: then no tile is dead
-  const bool row_full = tid < a.Lq && a.lse_in[2 * ((size_t)(b * a.h + head) * a.Lq + tid)] == MASK_FILL;
+  const bool row_full = tid < a.Lq && st_mx == MASK_FILL;
   const bool skip_ok = !__syncthreads_or(row_full) && !(GENERIC && a.full_mask);
 
   floatx16 dkacc[NU], dvacc[NU];

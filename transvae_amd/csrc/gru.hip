@@ -39,9 +39,11 @@ constexpr int RS = 2;                    // 16-row sub-tiles per workgroup: a st
 // A rows are `lda` floats apart, rows of W `ldw`; NG accumulators per sub-tile use W rows u0 + g * gstride + j.
 // A step is a chain of latencies around 1.25 us of MFMA time, so every operand byte of a batch of CH float4 per row is
 // requested before the first MFMA of the batch is issued (one memory round trip per batch, not one per float4), and a
-// workgroup covers 32 rows with one read of its W rows.
+// workgroup covers 32 rows with one read of its W rows.  CH divides the number of float4 per lane (the host picks it):
+// with a range test per chunk the compiler peeled the loop into load -> wait -> MFMA links, one round trip each; the
+// scheduling barrier keeps it from sinking loads below MFMAs to save registers (a step runs one wave per SIMD anyway).
 template <int NG, int CH>
-__device__ inline void tile_product(const float* __restrict__ A, long lda, int rows_valid, const float* __restrict__ W, int ldw,
+__device__ inline void tile_product(const float* __restrict__ A, int lda, int rows_valid, const float* __restrict__ W, int ldw,
                                     int gstride, int K, int wave, int lane, floatx4 (&acc)[RS][NG]) {
   const int i = lane & 15, kq = lane >> 4;
   const int kw = K >> 2;                 // this wave's share of K
@@ -52,31 +54,29 @@ __device__ inline void tile_product(const float* __restrict__ A, long lda, int r
   // k order: float4 c of lane-quarter kq is k = 16 c + 4 kq .. + 3 of the wave's share, so that ONE load instruction reads a
   // contiguous 64-byte run per row (16 runs per instruction; with each lane walking its own run it touched 32-64 cache lines
   // per instruction, 16 bytes from each, and the texture path's line rate bounded the step)
-  for (int s = 0; s < RS; ++s) ap[s] = A + (long)(16 * s + i < rows_valid ? 16 * s + i : 0) * lda + wave * kw + 4 * kq;
-  const float* wp = W + (long)i * ldw + wave * kw + 4 * kq;
+  for (int s = 0; s < RS; ++s) ap[s] = A + (16 * s + i < rows_valid ? 16 * s + i : 0) * lda + wave * kw + 4 * kq;
+  const float* wp = W + i * ldw + wave * kw + 4 * kq;
   for (int c0 = 0; c0 < nch; c0 += CH) {
     float4 a[RS][CH], b[NG][CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      const int cc = (c0 + c < nch) ? c0 + c : c0;            // past the end: repeat a valid chunk, skipped below
 #pragma unroll
-      for (int s = 0; s < RS; ++s) a[s][c] = *reinterpret_cast<const float4*>(ap[s] + 16 * cc);
+      for (int s = 0; s < RS; ++s) a[s][c] = *reinterpret_cast<const float4*>(ap[s] + 16 * (c0 + c));
 #pragma unroll
-      for (int g = 0; g < NG; ++g) b[g][c] = *reinterpret_cast<const float4*>(wp + (long)g * gstride * ldw + 16 * cc);
+      for (int g = 0; g < NG; ++g) b[g][c] = *reinterpret_cast<const float4*>(wp + g * gstride * ldw + 16 * (c0 + c));
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      if (c0 + c < nch) {
 #pragma unroll
-        for (int s = 0; s < RS; ++s)
+      for (int s = 0; s < RS; ++s)
 #pragma unroll
-          for (int g = 0; g < NG; ++g) {
-            acc[s][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][c].x, b[g][c].x, acc[s][g], 0, 0, 0);
-            acc[s][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][c].y, b[g][c].y, acc[s][g], 0, 0, 0);
-            acc[s][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][c].z, b[g][c].z, acc[s][g], 0, 0, 0);
-            acc[s][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][c].w, b[g][c].w, acc[s][g], 0, 0, 0);
-          }
-      }
+        for (int g = 0; g < NG; ++g) {
+          acc[s][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][c].x, b[g][c].x, acc[s][g], 0, 0, 0);
+          acc[s][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][c].y, b[g][c].y, acc[s][g], 0, 0, 0);
+          acc[s][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][c].z, b[g][c].z, acc[s][g], 0, 0, 0);
+          acc[s][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][c].w, b[g][c].w, acc[s][g], 0, 0, 0);
+        }
     }
   }
 }
@@ -104,83 +104,105 @@ __device__ inline void reduce_tiles(floatx4 (&acc)[RS][NG], float* red, int wave
     }
 }
 
-__global__ __launch_bounds__(256) void gru_fwd_step(GruArgs a) {
+// Per-thread addresses are a uniform 64-bit base (scalar arithmetic) plus a 32-bit offset inside the workgroup's 32 rows
+// (the host checks that 32 rows of the widest buffer stay below 2^31 floats): with 64-bit per-thread products the register
+// allocator paired the high word of an address with a register that a pending load was to fill, and the address
+// arithmetic of the NEXT load waited for that load -- a memory round trip in the middle of the prologue.
+template <int CH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void gru_fwd_step(GruArgs a) {
   __shared__ float red[4 * RS * 3 * 4 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b0 = blockIdx.x * 16 * RS, u0 = blockIdx.y * 16;
   const int H = a.H, t = a.t;
   const float* hprev_base = t > 0 ? a.hseq + ((long)b0 * a.sb + (long)(t - 1) * a.st) * H : (a.h0 ? a.h0 + (long)b0 * H : nullptr);
-  const long hprev_ld = t > 0 ? (long)a.sb * H : H;
+  const int hprev_ld = t > 0 ? a.sb * H : H;
+  const long row0 = (long)b0 * a.sb + (long)t * a.st;          // buffer row of the workgroup's first batch row
   // this thread's (rows, unit) and everything its gate arithmetic reads: requested before the product, used after it
   const int i = tid >> 4, j = tid & 15, u = u0 + j;
   const float br = a.b_hh[u], bz = a.b_hh[H + u], bn = a.b_hh[2 * H + u];
+  const float* gi0 = a.gi + row0 * 3 * H;
+  const float* hp0 = hprev_base ? hprev_base : a.gi;           // no initial state: any readable address, the value is dropped
   bool live[RS];
-  long row[RS];
+  int rel[RS];                                                 // row of this thread relative to row0, in buffer rows
   float gir[RS], giz[RS], gin[RS], hp[RS];
 #pragma unroll
   for (int s = 0; s < RS; ++s) {
-    const int b = b0 + 16 * s + i;
-    live[s] = b < a.B;
-    row[s] = (long)(live[s] ? b : b0) * a.sb + (long)t * a.st;
-    const float* gi = a.gi + row[s] * 3 * H;
+    live[s] = b0 + 16 * s + i < a.B;
+    const int lr = live[s] ? 16 * s + i : 0;
+    rel[s] = lr * a.sb;
+    const float* gi = gi0 + rel[s] * 3 * H;
     gir[s] = gi[u]; giz[s] = gi[H + u]; gin[s] = gi[2 * H + u];
-    hp[s] = hprev_base ? hprev_base[(long)(live[s] ? 16 * s + i : 0) * hprev_ld + u] : 0.f;
+    hp[s] = hp0[lr * hprev_ld + u];
   }
   floatx4 acc[RS][3];
 #pragma unroll
   for (int s = 0; s < RS; ++s)
 #pragma unroll
     for (int g = 0; g < 3; ++g) acc[s][g] = floatx4{0.f, 0.f, 0.f, 0.f};
-  if (hprev_base) tile_product<3, 4>(hprev_base, hprev_ld, a.B - b0, a.w + (long)u0 * H, H, H, H, wave, lane, acc);
+  if (hprev_base) tile_product<3, CH>(hprev_base, hprev_ld, a.B - b0, a.w + (long)u0 * H, H, H, H, wave, lane, acc);
   float gh[RS][3];
   reduce_tiles<3>(acc, red, wave, lane, tid, gh);
+  float* hs0 = a.hseq + row0 * H;
+  float* G0 = a.gates ? a.gates + row0 * 4 * H : nullptr;
 #pragma unroll
   for (int s = 0; s < RS; ++s) {
     if (!live[s]) continue;
     const float hr = gh[s][0] + br, hz = gh[s][1] + bz, hn = gh[s][2] + bn;
     const float r = sigmoidf_(gir[s] + hr), z = sigmoidf_(giz[s] + hz);
     const float n = tanhf(gin[s] + r * hn);
-    a.hseq[row[s] * H + u] = (1.f - z) * n + z * hp[s];
-    if (a.gates) {
-      float* G = a.gates + row[s] * 4 * H;
+    hs0[rel[s] * H + u] = (1.f - z) * n + z * (hprev_base ? hp[s] : 0.f);
+    if (G0) {
+      float* G = G0 + rel[s] * 4 * H;
       G[u] = r; G[H + u] = z; G[2 * H + u] = n; G[3 * H + u] = hn;
     }
   }
 }
 
-__global__ __launch_bounds__(256) void gru_bwd_step(GruArgs a) {
+template <int CH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void gru_bwd_step(GruArgs a) {
   __shared__ float red[4 * RS * 1 * 4 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b0 = blockIdx.x * 16 * RS, u0 = blockIdx.y * 16;
   const int H = a.H, t = a.t;
   const bool last = t == a.T - 1 && !a.continues;
   const int i = tid >> 4, j = tid & 15, u = u0 + j;
+  const long row0 = (long)b0 * a.sb + (long)t * a.st;
+  // the gate derivatives' inputs: requested before the product, every load unconditional (an operand that is absent is read
+  // from some readable address and dropped by a select: no branch whose join would wait for the loads before it)
+  const float* G0 = a.gates + row0 * 4 * H;
+  const float* dhs0 = a.dhseq ? a.dhseq + row0 * H : G0;
+  const float* add0 = last ? (a.dh_last ? a.dh_last + (long)b0 * H : G0) : a.carry + (long)b0 * H;   // [B, H] rows
+  const bool has_add = !last || a.dh_last;
+  const float* hp0 = t > 0 ? a.hseq + (row0 - a.st) * H : (a.h0 ? a.h0 + (long)b0 * H : G0);
+  const int hp_ld = t > 0 ? a.sb * H : H;
+  const bool has_hp = t > 0 || a.h0;
   bool live[RS];
-  long row[RS], bb[RS];
+  int rel[RS], lr[RS];
   float dh[RS], r[RS], z[RS], n[RS], hn[RS], hp[RS];
-  // the gate derivatives' inputs: requested before the product
 #pragma unroll
   for (int s = 0; s < RS; ++s) {
-    const int b = b0 + 16 * s + i;
-    live[s] = b < a.B;
-    bb[s] = live[s] ? b : b0;
-    row[s] = bb[s] * a.sb + (long)t * a.st;
-    dh[s] = a.dhseq ? a.dhseq[row[s] * H + u] : 0.f;
-    if (last) dh[s] += a.dh_last ? a.dh_last[bb[s] * H + u] : 0.f;
-    else dh[s] += a.carry[bb[s] * H + u];
-    const float* G = a.gates + row[s] * 4 * H;
+    live[s] = b0 + 16 * s + i < a.B;
+    lr[s] = live[s] ? 16 * s + i : 0;
+    rel[s] = lr[s] * a.sb;
+    const float d1 = dhs0[rel[s] * H + u], d2 = add0[lr[s] * H + u];
+    dh[s] = (a.dhseq ? d1 : 0.f) + (has_add ? d2 : 0.f);
+    const float* G = G0 + rel[s] * 4 * H;
     r[s] = G[u]; z[s] = G[H + u]; n[s] = G[2 * H + u]; hn[s] = G[3 * H + u];
-    hp[s] = t > 0 ? a.hseq[(row[s] - a.st) * H + u] : (a.h0 ? a.h0[bb[s] * H + u] : 0.f);
+    const float h1 = hp0[lr[s] * hp_ld + u];
+    hp[s] = has_hp ? h1 : 0.f;
   }
   floatx4 acc[RS][1];
 #pragma unroll
   for (int s = 0; s < RS; ++s) acc[s][0] = floatx4{0.f, 0.f, 0.f, 0.f};
   if (!last) {
     const float* dgh_next = a.dgh + ((long)b0 * a.sb + (long)(t + 1) * a.st) * 3 * H;
-    tile_product<1, 12>(dgh_next, (long)a.sb * 3 * H, a.B - b0, a.w + (long)u0 * 3 * H, 3 * H, 0, 3 * H, wave, lane, acc);
+    tile_product<1, CH>(dgh_next, a.sb * 3 * H, a.B - b0, a.w + (long)u0 * 3 * H, 3 * H, 0, 3 * H, wave, lane, acc);
   }
   float back[RS][1];
   reduce_tiles<1>(acc, red, wave, lane, tid, back);
+  float* dgi0 = a.dgi + row0 * 3 * H;
+  float* dgh0 = a.dgh + row0 * 3 * H;
+  float* carry0 = a.carry + (long)b0 * H;
 #pragma unroll
   for (int s = 0; s < RS; ++s) {
     if (!live[s]) continue;
@@ -188,11 +210,11 @@ __global__ __launch_bounds__(256) void gru_bwd_step(GruArgs a) {
     const float dn = d * (1.f - z[s]), dz = d * (hp[s] - n[s]);
     const float dnp = dn * (1.f - n[s] * n[s]);
     const float drp = dnp * hn[s] * r[s] * (1.f - r[s]), dzp = dz * z[s] * (1.f - z[s]);
-    float* dgi = a.dgi + row[s] * 3 * H;
-    float* dgh = a.dgh + row[s] * 3 * H;
+    float* dgi = dgi0 + rel[s] * 3 * H;
+    float* dgh = dgh0 + rel[s] * 3 * H;
     dgi[u] = drp; dgi[H + u] = dzp; dgi[2 * H + u] = dnp;
     dgh[u] = drp; dgh[H + u] = dzp; dgh[2 * H + u] = dnp * r[s];
-    a.carry[bb[s] * H + u] = d * z[s];
+    carry0[lr[s] * H + u] = d * z[s];
   }
 }
 
@@ -228,6 +250,8 @@ int check_gru(const char* who, int T, int B, int H, int time_major) {
   TVAE_CHECK(H % 64 == 0, TVAE_E_SHAPE, "%s: hidden size %d must be a multiple of 64", who, H);
   TVAE_CHECK(time_major == 0 || time_major == 1, TVAE_E_SHAPE, "%s: time_major must be 0 or 1", who);
   TVAE_CHECK((long)B * T * 4 * H < (1L << 40), TVAE_E_SHAPE, "%s: sequence buffer too large", who);
+  // 32-bit offsets inside a workgroup's 32 rows of the widest buffer ([.., 4H], rows T apart when batch-major), and in W_hh
+  TVAE_CHECK(32L * T * 4 * H < (1L << 31) && 3L * H * H < (1L << 31), TVAE_E_SHAPE, "%s: T * H = %ld exceeds the kernels' 32-bit row offsets", who, (long)T * H);
   return TVAE_OK;
 }
 
@@ -242,9 +266,11 @@ extern "C" int tvae_gru_fwd(const float* gi, const float* w_hh, const float* b_h
   a.gi = gi; a.w = w_hh; a.b_hh = b_hh; a.h0 = h0; a.hseq = hseq; a.gates = gates;
   a.T = T; a.B = B; a.H = H; a.sb = time_major ? 1 : T; a.st = time_major ? B : 1;
   const dim3 grid(cdiv(B, 16 * RS), H / 16);
+  const int nch = H / 64;              // float4 per lane and wave in the h W_hh^T product: chunks in flight = its largest divisor <= 4
+  auto kern = nch % 4 == 0 ? gru_fwd_step<4> : nch % 3 == 0 ? gru_fwd_step<3> : nch % 2 == 0 ? gru_fwd_step<2> : gru_fwd_step<1>;
   for (int t = 0; t < T; ++t) {
     a.t = t;
-    hipLaunchKernelGGL(gru_fwd_step, grid, dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, (hipStream_t)stream, a);
   }
   TVAE_LAUNCH_CHECK("tvae_gru_fwd");
   return TVAE_OK;
@@ -265,9 +291,11 @@ extern "C" int tvae_gru_bwd(const float* dhseq, const float* dh_last, const floa
   a.T = T; a.B = B; a.H = H; a.sb = time_major ? 1 : T; a.st = time_major ? B : 1;
   a.continues = continues;
   const dim3 grid(cdiv(B, 16 * RS), H / 16);
+  const int nch = 3 * H / 64;          // float4 per lane and wave in the dgh W_hh product (a multiple of 3)
+  auto kern = nch % 12 == 0 ? gru_bwd_step<12> : nch % 6 == 0 ? gru_bwd_step<6> : gru_bwd_step<3>;
   for (int t = T - 1; t >= 0; --t) {
     a.t = t;
-    hipLaunchKernelGGL(gru_bwd_step, grid, dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, (hipStream_t)stream, a);
   }
   TVAE_LAUNCH_CHECK("tvae_gru_bwd");
   return TVAE_OK;

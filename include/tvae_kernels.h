@@ -172,6 +172,9 @@ int tvae_layernorm_bwd(const float* x, const float* a, const float* dy, const fl
  *   lse (B, h, Lq, 2): {row max, 1 / row sum} of each score row, consumed by the backward
  *   p_out (B, h, Lq, Lk) or NULL: the softmax weights before dropout (MultiHeadedAttention.attn,
  *   forward_w_attn: transvae/trans_models.py:796-813, 866-880)
+ *   dtype: TVAE_F32 and TVAE_F32X3 run the products as exact fp32 MFMAs; TVAE_BF16 rounds their operands
+ *   to bf16 on the way into the bf16 matrix cores (softmax, statistics and masks stay fp32; a backward
+ *   call must use the dtype of its forward: it recomputes the forward's P).
  * Limits: Lq, Lk <= 128, dk in {32, 64}.
  */
 int tvae_attn_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,

@@ -19,6 +19,8 @@ def timeit(fn, iters=20):
 
 
 def main():
+    if len(sys.argv) > 1:                      # python tools/attn_bench.py bf16: the bf16-MFMA instantiations
+        ops.set_compute_dtype(sys.argv[1])
     B, h, dk = 500, 4, 64
     d = h * dk
     toks = synth.synth_tokens(B, seed=100)

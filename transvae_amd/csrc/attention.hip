@@ -66,12 +66,36 @@ __device__ inline void load_row_half(float (&reg)[HALF], const float* __restrict
   }
 }
 
+// bf16 arithmetic (dtype TVAE_BF16): the tiles stay fp32 in LDS and in registers and are rounded to bf16 on the way into
+// v_mfma_f32_32x32x16_bf16 -- eight consecutive k of the lane's half per instruction, two ds_read_b128 and four
+// v_cvt_pk_bf16_f32 per MFMA that does the work of eight fp32 ones.  Softmax, statistics, masks and accumulators are fp32.
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ inline unsigned pk2(float a, float b) {          // one v_cvt_pk_bf16_f32 (round to nearest even)
+  bf16x2v v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ inline bf16x8 pack8(const float (&f)[8]) {
+  u32x4 w = {pk2(f[0], f[1]), pk2(f[2], f[3]), pk2(f[4], f[5]), pk2(f[6], f[7])};
+  return __builtin_bit_cast(bf16x8, w);
+}
+
 // acc[i] (+)= sum over this k-tile of A_lds[row][hh*HALF + s] * breg[s]   (32 rows x 32 lanes)
-template <int DK>
+template <int DK, bool BF>
 __device__ inline floatx16 mma_rows_x_reg(const float* __restrict__ T, int row, int hh, const float (&breg)[DK / 2]) {
   constexpr int LS = DK + 4, HALF = DK / 2;
   floatx16 acc = zero16();
   const float* p = &T[row * LS + hh * HALF];
+  if (BF) {
+#pragma unroll
+    for (int s = 0; s < HALF; s += 8) {
+      const float4 a0 = *reinterpret_cast<const float4*>(p + s), a1 = *reinterpret_cast<const float4*>(p + s + 4);
+      const float af[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      const float bf[8] = {breg[s], breg[s + 1], breg[s + 2], breg[s + 3], breg[s + 4], breg[s + 5], breg[s + 6], breg[s + 7]};
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(af), pack8(bf), acc, 0, 0, 0);
+    }
+    return acc;
+  }
 #pragma unroll
   for (int s = 0; s < HALF; s += 4) {
     float4 a = *reinterpret_cast<const float4*>(p + s);
@@ -84,10 +108,28 @@ __device__ inline floatx16 mma_rows_x_reg(const float* __restrict__ T, int row, 
 }
 
 // out[u] += sum_i  T[(row0 + crow(i,hh))][32u + r] * breg[i]   (contraction over the 32 rows of a tile)
-template <int DK>
+template <int DK, bool BF>
 __device__ inline void mma_cols_x_acc(floatx16 (&out)[DK / 32], const float* __restrict__ T, int row0, int hh, int r,
                                       const floatx16& breg) {
   constexpr int LS = DK + 4;
+  if (BF) {
+    // k slot j of lane half hh in MFMA m is tile row crow(8 m + j, hh), in A and in B alike
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      float bf[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bf[j] = breg[8 * m + j];
+      const bf16x8 B = pack8(bf);
+#pragma unroll
+      for (int u = 0; u < DK / 32; ++u) {
+        float af[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) af[j] = T[(row0 + crow(8 * m + j, hh)) * LS + 32 * u + r];
+        out[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(af), B, out[u], 0, 0, 0);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const float* p = &T[(row0 + crow(i, hh)) * LS + r];
@@ -166,7 +208,7 @@ __device__ inline uint32_t drop_group(size_t prow, int t, int g, int hh) {
 // ------------------------------------------------------------------------------- forward
 // GENERIC = false: no (B,Lq,Lk) mask and no attention-weight dump -- the train-step instantiation,
 // free of the per-element branches those options need.
-template <int DK, bool GENERIC>
+template <int DK, bool GENERIC, bool BF>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   constexpr int LS = DK + 4, HALF = DK / 2, NU = DK / 32;
   __shared__ __attribute__((aligned(16))) float Ks[128 * LS];
@@ -200,7 +242,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     if (!live.t[t]) continue;
-    st[t] = mma_rows_x_reg<DK>(Ks, 32 * t + r, hh, qreg);
+    st[t] = mma_rows_x_reg<DK, BF>(Ks, 32 * t + r, hh, qreg);
     const uint32_t mw = mwf[t] >> (4 * hh);
     const int nk = a.Lk - 32 * t - 4 * hh;                 // keys of this tile with in-lane offset < nk exist
 #pragma unroll
@@ -266,7 +308,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         st[t][i] = p;
       }
     }
-    mma_cols_x_acc<DK>(oacc, Vs, 32 * t, hh, r, st[t]);
+    mma_cols_x_acc<DK, BF>(oacc, Vs, 32 * t, hh, r, st[t]);
   }
   if (qvalid) store_rowmajor<DK>(a.o_out + ((size_t)b * a.Lq + qi) * a.ldo + head * DK, oacc, hh);
 }
@@ -280,7 +322,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 // near-uniform source attention of this model that error was 3-4x the reference's own.)
 // Also leaves, for the dK/dV kernel: dsum per row and the dropout keep flags of the row as four
 // 32-bit words (that kernel holds the key on the lane and would need one hash per element).
-template <int DK, bool GENERIC>
+template <int DK, bool GENERIC, bool BF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 void attn_bwd_dq_kernel(AttnArgs a) {
   constexpr int LS = DK + 4, HALF = DK / 2, NU = DK / 32;
@@ -320,8 +362,8 @@ void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       if (!live.t[t]) continue;
-      pt[t] = mma_rows_x_reg<DK>(Ks, 32 * t + r, hh, qreg);
-      dpt[t] = mma_rows_x_reg<DK>(Vs, 32 * t + r, hh, doreg);
+      pt[t] = mma_rows_x_reg<DK, BF>(Ks, 32 * t + r, hh, qreg);
+      dpt[t] = mma_rows_x_reg<DK, BF>(Vs, 32 * t + r, hh, doreg);
     }
   }
   float dsum = 0.f, psum = 0.f;
@@ -382,7 +424,7 @@ void attn_bwd_dq_kernel(AttnArgs a) {
       const float ds = ((mwt[t] >> crow(i, 0)) & 1U) ? pt[t][i] * (dpt[t][i] - dsum) * a.scale : 0.f;
       dpt[t][i] = ds;
     }
-    mma_cols_x_acc<DK>(dqacc, Ks, 32 * t, hh, r, dpt[t]);
+    mma_cols_x_acc<DK, BF>(dqacc, Ks, 32 * t, hh, r, dpt[t]);
   }
   if (qvalid) store_rowmajor<DK>(a.dq + ((size_t)b * a.Lq + qi) * a.lddq + head * DK, dqacc, hh);
 }
@@ -391,7 +433,7 @@ void attn_bwd_dq_kernel(AttnArgs a) {
 // Key on the lane: S = Q K^T and dP = dO V^T come out as [query regs][key lanes], which is the
 // B operand of dV^T = dO^T P and dK^T = Q^T dS directly.  Row statistics, dsum and the dropout keep
 // words come from the dQ kernel's workspace (one LDS broadcast read per query).
-template <int DK, bool GENERIC>
+template <int DK, bool GENERIC, bool BF>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
   constexpr int LS = DK + 4, HALF = DK / 2, NU = DK / 32;
   __shared__ __attribute__((aligned(16))) float Qs[128 * LS];
@@ -445,8 +487,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     const int q_last = min(32 * t + 31, a.Lq - 1);
     const bool lane_live = kbit && q_last >= 32 * t && (!a.causal || key <= q_last);
     if (skip_ok && __ballot(lane_live) == 0ULL) continue;
-    floatx16 s = mma_rows_x_reg<DK>(Qs, 32 * t + r, hh, kreg);
-    floatx16 dp = mma_rows_x_reg<DK>(Gs, 32 * t + r, hh, vreg);
+    floatx16 s = mma_rows_x_reg<DK, BF>(Qs, 32 * t + r, hh, kreg);
+    floatx16 dp = mma_rows_x_reg<DK, BF>(Gs, 32 * t + r, hh, vreg);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       int qi = 32 * t + crow(i, hh);
@@ -465,13 +507,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
       s[i] = pt;
       dp[i] = ds;
     }
-    mma_cols_x_acc<DK>(dvacc, Gs, 32 * t, hh, r, s);
-    mma_cols_x_acc<DK>(dkacc, Qs, 32 * t, hh, r, dp);
+    mma_cols_x_acc<DK, BF>(dvacc, Gs, 32 * t, hh, r, s);
+    mma_cols_x_acc<DK, BF>(dkacc, Qs, 32 * t, hh, r, dp);
   }
   if (kvalid) {
     store_rowmajor<DK>(a.dk + ((size_t)b * a.Lk + key) * a.lddk + head * DK, dkacc, hh);
     store_rowmajor<DK>(a.dv + ((size_t)b * a.Lk + key) * a.lddv + head * DK, dvacc, hh);
   }
+}
+
+typedef void (*AttnKernel)(AttnArgs);
+// (dk == 64, generic, bf16) -> one of the eight instantiations, listed as <64,T,T> <64,T,F> <64,F,T> <64,F,F> <32,...>
+AttnKernel pick(bool d64, bool generic, bool bf, AttnKernel a0, AttnKernel a1, AttnKernel a2, AttnKernel a3, AttnKernel b0,
+                AttnKernel b1, AttnKernel b2, AttnKernel b3) {
+  const AttnKernel t[8] = {a0, a1, a2, a3, b0, b1, b2, b3};
+  return t[(d64 ? 0 : 4) + (generic ? 0 : 2) + (bf ? 0 : 1)];
 }
 
 int check_common(const char* who, int B, int h, int Lq, int Lk, int dk, const int* lds, int nld, const void* const* ptrs,
@@ -506,13 +556,11 @@ extern "C" int tvae_attn_fwd(const float* q, int ldq, const float* k, int ldk, c
   a.B = B; a.h = h; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.rng = rng; a.site = site; a.p = p_drop;
   hipStream_t s = (hipStream_t)stream;
   const bool generic = full_mask || p_out;
-  if (dk == 64) {
-    if (generic) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), dim3(B * h), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<64, false>), dim3(B * h), dim3(256), 0, s, a);
-  } else {
-    if (generic) hipLaunchKernelGGL((attn_fwd_kernel<32, true>), dim3(B * h), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<32, false>), dim3(B * h), dim3(256), 0, s, a);
-  }
+  // dtype BF16: the four products on the bf16 matrix cores; F32 and F32X3 (whose promise is fp32 accuracy): exact fp32 MFMAs
+  auto kern = pick(dk == 64, generic, dtype == TVAE_BF16,
+                   attn_fwd_kernel<64, true, true>, attn_fwd_kernel<64, true, false>, attn_fwd_kernel<64, false, true>, attn_fwd_kernel<64, false, false>,
+                   attn_fwd_kernel<32, true, true>, attn_fwd_kernel<32, true, false>, attn_fwd_kernel<32, false, true>, attn_fwd_kernel<32, false, false>);
+  hipLaunchKernelGGL(kern, dim3(B * h), dim3(256), 0, s, a);
   TVAE_LAUNCH_CHECK("tvae_attn_fwd");
   return TVAE_OK;
 }
@@ -536,23 +584,15 @@ extern "C" int tvae_attn_bwd(const float* q, int ldq, const float* k, int ldk, c
   a.B = B; a.h = h; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.rng = rng; a.site = site; a.p = p_drop;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(B * h), block(256);
-  if (dk == 64) {
-    if (full_mask) {
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<64, true>), grid, block, 0, s, a);
-      hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, true>), grid, block, 0, s, a);
-    } else {
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<64, false>), grid, block, 0, s, a);
-      hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, false>), grid, block, 0, s, a);
-    }
-  } else {
-    if (full_mask) {
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<32, true>), grid, block, 0, s, a);
-      hipLaunchKernelGGL((attn_bwd_dkv_kernel<32, true>), grid, block, 0, s, a);
-    } else {
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<32, false>), grid, block, 0, s, a);
-      hipLaunchKernelGGL((attn_bwd_dkv_kernel<32, false>), grid, block, 0, s, a);
-    }
-  }
+  const bool bf = dtype == TVAE_BF16, gen = full_mask != nullptr;
+  auto kq = pick(dk == 64, gen, bf,
+                 attn_bwd_dq_kernel<64, true, true>, attn_bwd_dq_kernel<64, true, false>, attn_bwd_dq_kernel<64, false, true>, attn_bwd_dq_kernel<64, false, false>,
+                 attn_bwd_dq_kernel<32, true, true>, attn_bwd_dq_kernel<32, true, false>, attn_bwd_dq_kernel<32, false, true>, attn_bwd_dq_kernel<32, false, false>);
+  auto kkv = pick(dk == 64, gen, bf,
+                  attn_bwd_dkv_kernel<64, true, true>, attn_bwd_dkv_kernel<64, true, false>, attn_bwd_dkv_kernel<64, false, true>, attn_bwd_dkv_kernel<64, false, false>,
+                  attn_bwd_dkv_kernel<32, true, true>, attn_bwd_dkv_kernel<32, true, false>, attn_bwd_dkv_kernel<32, false, true>, attn_bwd_dkv_kernel<32, false, false>);
+  hipLaunchKernelGGL(kq, grid, block, 0, s, a);
+  hipLaunchKernelGGL(kkv, grid, block, 0, s, a);
   TVAE_LAUNCH_CHECK("tvae_attn_bwd");
   return TVAE_OK;
 }

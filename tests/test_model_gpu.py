@@ -405,6 +405,36 @@ def test_fused_chunks_equal_literal_chunk_loop():
             assert rel_l2(grads[0][k], grads[1][k]) < 2e-5, k
 
 
+def test_packed_qkv_projections_equal_separate_ones(monkeypatch):
+    """VAEShell lays q, k, v out as row blocks of one matrix and runs one GEMM for the three (exact-fp32 mode).  Against
+    the same model with separately allocated projections (TVAE_PACK_QKV=0): identical forward losses (each output element
+    is the same chain of products), gradients equal to rounding; parameter names and shapes untouched."""
+    from transvae_amd import synth, ops
+    toks = synth.synth_tokens(16, seed=5).float()
+    data = torch.cat([toks, torch.zeros(16, 1)], 1)
+    eps = torch.randn(16, 128, generator=torch.Generator().manual_seed(3)).cuda()
+    grads, tables, names = [], [], []
+    for pack in ("1", "0"):
+        monkeypatch.setenv("TVAE_PACK_QKV", pack)
+        vae = build("1x128_zinc", BATCH_SIZE=16, BATCH_CHUNKS=2)
+        lin = vae.model.encoder.layers[0].self_attn.linears
+        adjacent = ops._adjacent(lin[0].weight, lin[1].weight, lin[2].weight) and ops._adjacent(lin[0].weight.grad, lin[1].weight.grad, lin[2].weight.grad) \
+            if lin[0].weight.grad is not None else False
+        assert adjacent == (pack == "1")
+        vae.model.eval()
+        vae.optimizer.optimizer.fuse_zero_grad = False
+        tables.append(vae.train_step(data, 0.03, eps=eps).cpu().numpy())
+        grads.append({k: p.grad.detach().cpu().numpy().copy() for k, p in vae.model.named_parameters()})
+        names.append([(k, tuple(v.shape)) for k, v in vae.model.state_dict().items()])
+    assert names[0] == names[1]
+    assert np.array_equal(tables[0], tables[1])
+    for k in grads[0]:
+        if k.endswith("attn.linears.1.bias"):
+            assert np.linalg.norm(grads[0][k]) < 1e-5 and np.linalg.norm(grads[1][k]) < 1e-5
+        else:
+            assert rel_l2(grads[0][k], grads[1][k]) < 1e-5, k
+
+
 def test_reference_written_checkpoint_decodes_to_the_reference_tokens():
     """tests/golden/ref_tiny.ckpt (written by the reference's VAEShell.save, read here by the safe loader) must put the
     model in the state the reference decoded from: mask lengths and greedy tokens bit for bit (ref_ckpt.npz)."""

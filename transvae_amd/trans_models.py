@@ -80,6 +80,22 @@ class MultiHeadedAttention(_Sited):
             out += [lin.weight, lin.bias]
         return out
 
+    def pack_qkv(self):
+        """Lay the q, k, v projections (weights, biases and their gradients) out as row blocks of one matrix each.  The
+        parameters keep their names, shapes and values; ops.AttnSublayerFn finds them adjacent and runs one GEMM for the
+        three (two for source attention) in the forward, the data gradient and the weight gradient.  Call after the
+        module is on its device and before the optimizer is built."""
+        lins = self.linears[:3]
+        d = lins[0].weight.shape[0]
+        w = torch.cat([l.weight.data for l in lins], 0)
+        b = torch.cat([l.bias.data for l in lins], 0)
+        gw, gb = torch.zeros_like(w), torch.zeros_like(b)
+        for i, l in enumerate(lins):
+            l.weight = nn.Parameter(w[i * d:(i + 1) * d])
+            l.bias = nn.Parameter(b[i * d:(i + 1) * d])
+            l.weight.grad = gw[i * d:(i + 1) * d]
+            l.bias.grad = gb[i * d:(i + 1) * d]
+
     def forward(self, query, key, value, mask=None, return_attn=False):
         B, Lq, _ = query.shape
         Lk = key.shape[1]
@@ -950,6 +966,10 @@ class TransVAE(VAEShell):
         if self.use_gpu:
             self.model.cuda()
             self.params['CHAR_WEIGHTS'] = self.params['CHAR_WEIGHTS'].cuda()
+            if os.environ.get("TVAE_PACK_QKV", "1") == "1":       # 0: keep the projections as separately allocated matrices
+                for m in self.model.modules():
+                    if isinstance(m, MultiHeadedAttention):
+                        m.pack_qkv()
         adam = Adam(self.model.parameters(), lr=0, betas=(0.9, 0.98), eps=1e-9)
         adam.fuse_zero_grad = True
         self.optimizer = NoamOpt(p['d_model'], p['LR_SCALE'], p['WARMUP_STEPS'], adam)

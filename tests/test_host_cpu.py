@@ -156,3 +156,35 @@ def test_sample_from_memory_matches_the_reference_draw_for_draw():
     assert np.array_equal(vae.sample_from_memory(5, mode="k_dims", sample_dims=pool, k=5).numpy(), g["k_dims_again"])
     with pytest.raises(AssertionError):
         vae.sample_from_memory(3, mode="top_dims")
+
+
+def test_pack_qkv_keeps_names_values_and_adjacency():
+    """MultiHeadedAttention.pack_qkv lays q, k, v (weights, biases, gradients) out as row blocks of one matrix: parameter
+    names, shapes and values are untouched, ops._adjacent sees the three as one run, load_state_dict (an in-place copy) keeps it;
+    deepcopy clones every Parameter on its own, which un-packs the copy (ops then runs the three GEMMs of before), and a
+    tensor that is merely equal but allocated elsewhere is not taken for adjacent."""
+    import copy
+    import torch
+    from transvae_amd import ops
+    from transvae_amd.trans_models import MultiHeadedAttention
+    torch.manual_seed(0)
+    m = MultiHeadedAttention(4, 64)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    lin = m.linears
+    assert not ops._adjacent(lin[0].weight, lin[1].weight, lin[2].weight)
+    m.pack_qkv()
+    after = m.state_dict()
+    assert list(after) == list(before) and all(torch.equal(after[k], before[k]) for k in before)
+    assert ops._adjacent(lin[0].weight, lin[1].weight, lin[2].weight) and ops._adjacent(lin[0].bias, lin[1].bias, lin[2].bias)
+    assert ops._adjacent(lin[0].weight.grad, lin[1].weight.grad, lin[2].weight.grad)
+    assert not ops._adjacent(lin[2].weight, lin[3].weight)              # the output projection is not part of the run
+    run = ops._run([lin[0].weight, lin[1].weight, lin[2].weight])
+    assert run.shape == (192, 64) and torch.equal(run, torch.cat([before["linears.%d.weight" % i] for i in range(3)], 0))
+    m.load_state_dict({k: v + 1 for k, v in before.items()})
+    assert ops._adjacent(lin[0].weight, lin[1].weight, lin[2].weight) and torch.equal(run[64:128], before["linears.1.weight"] + 1)
+    m2 = copy.deepcopy(m)
+    l2 = m2.linears
+    assert not ops._adjacent(l2[0].weight, l2[1].weight, l2[2].weight)
+    m2.pack_qkv()
+    assert ops._adjacent(l2[0].weight, l2[1].weight, l2[2].weight) and torch.equal(l2[1].weight, lin[1].weight)
+    assert not ops._adjacent(lin[0].weight, lin[1].weight.detach().clone())

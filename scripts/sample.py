@@ -31,15 +31,25 @@ def sample(args):
         sample_dims = np.where(np.array(calc_entropy(mus)) > args.entropy_cutoff)[0]
         sample_mode = 'top_dims' if args.sample_mode == 'high_entropy' else 'k_dims'
 
-    # every rank decodes its share in batches of n_samples_per_batch (the reference's loop, :47-51, over-shoots to whole
-    # batches); what travels between ranks is ONE gather of token ids, one byte each (26-token vocabulary)
+    # The reference decodes batch by batch (:47-51, over-shooting to whole batches of n_samples_per_batch); a 100-latent
+    # decode is launch-bound, so here only the LATENTS are drawn batch by batch -- same calls in the same order, hence the
+    # same z for the same seed -- and all of a rank's latents are decoded together in slabs of up to 65,536
+    # (VAEShell.decode_latents: rows are independent, the tokens are those of the per-batch loop).  TVAE_SAMPLE_PER_BATCH=1
+    # restores the literal loop.  What travels between ranks is ONE gather of token ids, one byte each (26-token vocabulary).
     def n_batches(r):
         share = args.n_samples // world + (1 if r < args.n_samples % world else 0)
         return -(-share // args.n_samples_per_batch)
-    ids = [vae.sample(args.n_samples_per_batch, sample_mode=sample_mode, sample_dims=sample_dims, k=args.k,
-                      condition=condition, return_str=False) for _ in range(n_batches(rank))]
     import torch
-    ids = torch.cat(ids).to(torch.uint8) if ids else torch.empty((0, vae.tgt_len), dtype=torch.uint8)
+    dev = vae._device()
+    if os.environ.get('TVAE_SAMPLE_PER_BATCH') == '1':
+        ids = [vae.sample(args.n_samples_per_batch, sample_mode=sample_mode, sample_dims=sample_dims, k=args.k,
+                          condition=condition, return_str=False).to(torch.uint8) for _ in range(n_batches(rank))]
+        ids = torch.cat(ids) if ids else torch.empty((0, vae.tgt_len), dtype=torch.uint8, device=dev)
+    else:
+        zs = [vae.sample_from_memory(args.n_samples_per_batch, mode=sample_mode, sample_dims=sample_dims, k=args.k)
+              for _ in range(n_batches(rank))]
+        ids = vae.decode_latents(torch.cat(zs), condition=condition) if zs \
+            else torch.empty((0, vae.tgt_len), dtype=torch.uint8, device=dev)     # on the model's device even when empty
     if world > 1:
         rows = [n_batches(r) * args.n_samples_per_batch for r in range(world)]
         padded = torch.zeros((max(rows), ids.shape[1]), dtype=torch.uint8, device=ids.device)
@@ -51,7 +61,7 @@ def sample(args):
         if rank == 0:
             ids = torch.cat([part[:n] for part, n in zip(parts, rows)])
         dist.destroy_process_group()
-    samples = decode_mols(ids.long().cpu(), vae.params['ORG_DICT']) if rank == 0 else []
+    samples = decode_mols(ids, vae.params['ORG_DICT']) if rank == 0 else []
     if rank == 0:
         save_path = args.save_path
         if save_path is None:

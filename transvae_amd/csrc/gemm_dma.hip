@@ -46,7 +46,9 @@ struct Dma {
   static constexpr int STAGE = A_BYTES + B_BYTES;
   static constexpr int A_TOTAL = A_BYTES / 1024, B_TOTAL = B_BYTES / 1024;            // DMA instructions per k-tile
   static constexpr int A_INSTR = (A_TOTAL + NWAVES - 1) / NWAVES, B_INSTR = B_TOTAL / NWAVES;   // ... per wave
-  static_assert(B_TOTAL % NWAVES == 0 && (A_TOTAL % NWAVES == 0 || A_TOTAL < NWAVES), "DMA split");
+  // every wave issues the SAME number of DMAs per k-tile: the counted wait below (vmcnt(PER_TILE)) is only right for a wave
+  // whose own count per tile is PER_TILE -- one that issued fewer would let a DMA of the tile about to be read stay in flight
+  static_assert(B_TOTAL % NWAVES == 0 && A_TOTAL % NWAVES == 0, "DMA split: equal shares per wave");
   static constexpr int S = 3;                               // k-tiles resident (one being read, two in flight / landed)
   static constexpr int EPI = NWAVES * 32 * 68 * 4;
   static constexpr int LDS_BYTES = (S * STAGE > EPI) ? S * STAGE : EPI;
@@ -97,8 +99,7 @@ void gemm_dma_kernel(GemmArgs g) {
   const int tile_n = wgid % ntn, tile_m = wgid / ntn;
   const int m0 = tile_m * BM, n0 = tile_n * D::TN;
   const int nkt = g.K / BK;
-  // with more waves than A instructions (16 waves, 16 instructions of 8 rows) every wave issues one; with fewer, several
-  const bool a_mine = (D::A_TOTAL >= D::NWAVES) || (wave < D::A_TOTAL);
+  constexpr bool a_mine = true;      // equal shares per wave (static_assert in Dma)
 
   // ---- per-lane DMA sources (advanced by one k-tile per issue) ----------------------------------------------
   constexpr int A_CPR = D::A_ROWB / 16, B_CPR = D::B_ROWB / 16;       // 16-byte chunks per row
@@ -162,7 +163,6 @@ void gemm_dma_kernel(GemmArgs g) {
     // tile t has landed once at most the DMAs of the tiles issued after it are outstanding; then the barrier makes the
     // other waves' parts visible and tells everybody that stage (t-1) % S is no longer being read
     if (t + 1 < nkt) {
-      // (a wave that issues fewer than PER_TILE -- none today -- would only wait longer than it has to)
       static_assert(PER_TILE == 6 || PER_TILE == 4 || PER_TILE == 3, "vmcnt literal");
       if (PER_TILE == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       else if (PER_TILE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");

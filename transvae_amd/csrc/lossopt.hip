@@ -54,7 +54,9 @@ __device__ inline LossArgs for_group(LossArgs a, int g) {
 constexpr int LOSS_STAGE_MAX = 33;          // row pitches up to this many floats are staged (256 * 33 * 4 = 33 KB)
 __device__ inline const float* stage_logit_rows(const LossArgs& a, float* tile, int row0, int rows, int tid) {
   const int nrow = min(256, rows - row0);
-  if (a.ldl > LOSS_STAGE_MAX || nrow <= 0) return nullptr;
+  // only rows without padding columns are staged: with ldl > n_cls the contiguous run would read past the last row's
+  // n_cls floats and the write-back would touch padding columns of dlogits (a column view of a wider matrix)
+  if (a.ldl != a.n_cls || a.ldl > LOSS_STAGE_MAX || nrow <= 0) return nullptr;
   const float* src = a.logits + (size_t)row0 * a.ldl;
   const int total = nrow * a.ldl;
   for (int i = tid; i < total; i += 256) tile[i] = src[i];
@@ -166,7 +168,6 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(LossArgs a0) {
     } else {
       for (int c = 0; c < a.n_cls; ++c) dl[c] = 0.f;
     }
-    for (int c = a.n_cls; staged && c < a.ldl; ++c) dl[c] = 0.f;     // padding columns of a staged row (none in the model)
   }
   if (staged) {                                       // the block's gradient rows leave as one coalesced run
     __syncthreads();

@@ -57,9 +57,12 @@ _rng = {}
 #               EncoderDecoder.encode bumps on every training-mode forward.  The Drop object made in the forward carries
 #               the combined number into the backward, so a plain `loss.backward()` loop over vae.model (no train_step),
 #               and the unfused chunk loop, draw fresh masks on every forward all the same.
-# Nothing here follows torch.manual_seed by itself: VAEShell.train seeds from torch.initial_seed() + rank unless
-# seed_rng was called explicitly, and rng_snapshot / rng_restore carry {seed, step, pass} through a checkpoint.
+# Nothing here follows torch.manual_seed by itself: the FIRST VAEShell.train of a process on a device seeds it from
+# torch.initial_seed() + rank unless seed_rng / rng_restore already did; every later train() call continues the stream
+# {seed, step, pass} where it stands (the reference continues torch's global generator the same way), and
+# rng_snapshot / rng_restore carry it through a checkpoint.
 _pass = {"n": 0, "explicit_seed": False}
+_seeded = set()
 
 
 def rng_state(device):
@@ -76,6 +79,12 @@ def seed_rng(device, seed, step=0, n_pass=0, explicit=True):
     st.copy_(torch.tensor([seed & 0x7FFFFFFF, step & 0x7FFFFFFF], dtype=torch.int32))
     _pass["n"] = int(n_pass)
     _pass["explicit_seed"] = bool(explicit)
+    _seeded.add((device.type, device.index))
+
+
+def rng_seeded(device):
+    "has the dropout stream of `device` been seeded (by the caller, a checkpoint or an earlier train())?"
+    return (device.type, device.index) in _seeded
 
 
 def seeded_explicitly():

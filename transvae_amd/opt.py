@@ -96,6 +96,10 @@ class AdamOpt:
         self.optimizer.step()
         self.state_dict = self.optimizer.state_dict()
 
+    def sync_state_dict(self):
+        "same call as NoamOpt's (VAEShell.train makes it before every checkpoint): refresh the dict attribute"
+        self.state_dict = self.optimizer.state_dict()
+
     def load_state_dict(self, state_dict):
         self.state_dict = state_dict
 

@@ -703,13 +703,15 @@ class VAEShell():
             from .parallel import DataParallel, mean_over_ranks
             dp = self._data_parallel()
             log, save = log and rank == 0, save and rank == 0
-        # dropout stream: continue the one a checkpoint carried, else follow torch's seed (+ rank, so that the replicas
-        # of a data-parallel run do not all drop the same units) unless the caller seeded it (ops.seed_rng)
+        # dropout stream: continue the one a checkpoint carried; else, ONCE per process and device, follow torch's seed
+        # (+ rank, so that the replicas of a data-parallel run do not all drop the same units) unless the caller seeded
+        # it (ops.seed_rng).  A later train() call -- train(epochs=1) in a loop, or again after a resume -- continues
+        # the stream {seed, step, pass} where the previous call left it instead of replaying the masks from step 0.
         if self.current_state['params'].get('RNG_STATE') is not None and self.loaded_from is not None \
                 and not getattr(self, '_rng_resumed', False):
             ops.rng_restore(self._device(), self.current_state['params']['RNG_STATE'])
             self._rng_resumed = True
-        elif not ops.seeded_explicitly():
+        elif not ops.rng_seeded(self._device()):
             ops.seed_rng(self._device(), (torch.initial_seed() + rank) & 0x7FFFFFFF, explicit=False)
 
         # the encoded molecules move to HBM once (one byte per token); a batch is one gather launch in the
@@ -832,6 +834,22 @@ class VAEShell():
                 mem, key_mask, self.params['CHAR_DICT']['<start>'], cond, self.tgt_len)
         finally:
             self.model.train(was_training)
+
+    DECODE_SLAB = 65536     # latents per greedy_decode call of decode_latents: ~110 GB of K/V caches for trans4x-256
+
+    @torch.no_grad()
+    def decode_latents(self, mem, condition=[], slab=None):
+        """greedy_decode over ANY number of latents: slabs of up to `slab` rows (default DECODE_SLAB) go through the
+        KV-cached decoder one after the other, the token ids come back as ONE (n, 125) uint8 tensor on the device (the
+        vocabulary has 26 entries: 1 M molecules are 125 MB instead of 1 GB of int64).  Rows are independent and the
+        kernels sum in a fixed order, so the tokens equal those of greedy_decode on any other split of `mem`."""
+        slab = int(slab or self.DECODE_SLAB)
+        dev = self._device()
+        n = mem.shape[0]
+        out = torch.empty((n, self.tgt_len), dtype=torch.uint8, device=dev)
+        for s0 in range(0, n, slab):
+            out[s0:s0 + slab] = self.greedy_decode(mem[s0:s0 + slab], condition=condition).to(torch.uint8)
+        return out
 
     @torch.no_grad()
     def _rnn_greedy_decode(self, mem, condition=[]):

@@ -90,18 +90,18 @@ def encode_smiles(smile, max_len, char_dict):
 
 def decode_mols(encoded_tensors, org_dict):
     """ids (n, L) -> strings: tokens until '<end>', pads stripped (reference tvae_util.py:152-166).
-    One device->host copy for the whole batch instead of one per row."""
-    arr = encoded_tensors.detach().cpu().numpy() - 1
-    mols = []
-    for row in arr:
-        s = ''
-        for idx in row:
-            tok = org_dict[int(idx)]
-            if tok == '<end>':
-                break
-            s += tok
-        mols.append(s.strip('_'))
-    return mols
+    One device->host copy for the whole batch instead of one per row; the cut at '<end>' is found for all rows at once
+    and a row is one table lookup + join (a million rows of uint8 ids take seconds, not minutes)."""
+    arr = encoded_tensors.detach().cpu().numpy().astype(np.int16) - 1
+    if arr.size == 0:
+        return ['' for _ in range(arr.shape[0])]
+    n_tok = max(org_dict.keys()) + 1
+    if arr.min() < 0 or arr.max() >= n_tok:
+        raise KeyError(int(arr.min() if arr.min() < 0 else arr.max()))      # what org_dict[idx] raises in the reference
+    lut = np.array([org_dict[i] for i in range(n_tok)], dtype=object)       # KeyError on a gap, as the reference
+    is_end = arr == [i for i in range(n_tok) if org_dict[i] == '<end>'][0]
+    ends = np.where(is_end.any(1), is_end.argmax(1), arr.shape[1])
+    return [''.join(lut[row[:e]]).strip('_') for row, e in zip(arr, ends)]
 
 
 def calc_entropy(sample):

@@ -210,6 +210,9 @@ int tvae_embed_bwd(const int64_t* ids, const float* dout, float* dlut, int B, in
  * x[b, t:t+k, :] and Conv1d becomes one tvae_gemm with lda = C, K = k*C over all B*L rows
  * (rows whose window crosses a molecule boundary are computed and ignored).
  *   conv weight (Cout, Cin, k) -> GEMM weight (Cout, k*Cin)           [tvae_conv_w_pack]
+ *   and back for its gradient [tvae_conv_w_unpack_grad]; there bit 1 of transposed_flip says that dwp arrives
+ *   transposed, (k*Cin, Cout): the weight-gradient product with its operands swapped, so that N = Cout (148 / 160
+ *   channels) lies on the 160-wide tile of tvae_gemm instead of M on two 128-row tiles
  *   pool: y[b,t,c] = relu(max(conv[b,2t,c], conv[b,2t+1,c])), t < Lp = Lconv/2 ; out_cm: y is
  *         written channel-major (B, C, Lp), the layout trans_models.py:789 flattens
  *   pool_bwd: dconv[b,t',c] = dy routed to the arg-max element when y > 0, zero elsewhere,
@@ -241,6 +244,21 @@ int tvae_upsample_fwd(const float* x, int src_rows, int src_cm, float* up, int B
                       int stride, int lpad, int Lup, void* stream);
 int tvae_upsample_bwd(const float* dup, const float* y, float* dx, int dst_rows, int dst_cm, int B,
                       int Lin, int C, int stride, int lpad, int Lup, void* stream);
+/*
+ * ConvTranspose1d with stride s > 1 (transvae/trans_models.py:1001-1009, nn.ConvTranspose1d at :995-998) as a POLYPHASE
+ * product: output position t + pad = m s + r only receives the taps j = r + s q (q < Q = ceil(k/s)) from the inputs
+ * i = m - q, so all s phases are ONE tvae_gemm over the un-upsampled input (Q - 1 leading zero rows per molecule,
+ * tvae_upsample_fwd with stride 1 / lpad Q-1): A rows overlap (lda = Cin, K = Q Cin), N = s Cout, and the output rows
+ * (b, m) x (r, co) are the token-major rows (b, m s + r) x co.  The FLOPs are those of the transposed convolution itself
+ * (the zero-stuffed form multiplies s - 1 zero rows out of s).  The data gradient is the same shape of product over the
+ * gradient rows (lda = s Cout, K = Q s Cout, N = Cin), the weight gradient a split-K product into the mode-0 layout.
+ *   mode 0: w (Cin, Cout, k) -> out (s Cout, Q Cin), out[(r,co),(qq,ci)] = w[ci,co, r + s (Q-1-qq)] (0 if >= k);
+ *           bias_out (s Cout) = bias_in tiled s times (either may be NULL)
+ *   mode 1: w -> out (Cin, Q s Cout), out[ci,(q,r,co)] = w[ci,co, r + s q] (0 if >= k): weight of the data gradient
+ *   mode 2: in = weight gradient in the mode-0 layout -> out (Cin, Cout, k); bias_out[co] = sum_r bias_in[(r,co)]
+ */
+int tvae_deconv_poly_pack(const float* in, float* out, const float* bias_in, float* bias_out, int Cin, int Cout,
+                          int k, int stride, int mode, void* stream);
 
 /* z = mu + eps*eps_scale*exp(0.5*logvar) (transvae/trans_models.py:771-775) and its backward
  * (dmu += dz ; dlogvar += dz*eps*eps_scale*0.5*exp(0.5*logvar)). */

@@ -64,6 +64,38 @@ def test_gemm_dgrad_wgrad(M, N, K):
     assert rel_l2(dm.cpu(), (dy @ w) * 1.25 * (mask > 0)) < TOL
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 160, 512), (333, 148, 768), (128, 160, 256), (2000, 132, 1040)])
+def test_gemm_wide_tile_nt(M, N, K, monkeypatch):
+    """N in (128, 160] goes to the 128 x 160 tile kernel (gemm_wide.hip): bias / ReLU / alpha, ragged M and N, and
+    overlapping A rows (lda < K: the conv bottleneck's im2col-free operand)"""
+    from transvae_amd import ops
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3)
+    y = ops.linear_fwd(g32(x), g32(w), g32(b), relu=True)
+    assert rel_l2(y.cpu(), torch.relu(x @ w.T + b)) < TOL
+    y = ops.linear_fwd(g32(x), g32(w), None)
+    assert rel_l2(y.cpu(), x @ w.T) < TOL
+    # overlapping rows: row r of A is flat[r*64 : r*64 + K]
+    flat = rnd(M * 64 + K, seed=4)
+    A = torch.stack([flat[r * 64:r * 64 + K] for r in range(M)])
+    out = torch.empty((M, N), device=dev(), dtype=torch.float32)
+    fg = g32(flat)
+    ops.gemm(fg, 64, g32(w), K, out, N, M, N, K, bias=g32(b), alpha=0.5)
+    assert rel_l2(out.cpu(), 0.5 * (A @ w.T) + b) < TOL
+
+
+@pytest.mark.parametrize("M,N,K", [(2304, 160, 9999), (260, 148, 4100), (128, 160, 300)])
+def test_gemm_wide_tile_tn_splitk(M, N, K):
+    "the weight-gradient form on the wide tile: both operands k-major, split-K atomics, a partial last k-step"
+    from transvae_amd import ops
+    a, b = rnd(K, M, seed=5), rnd(K, N, seed=6)
+    out = torch.zeros((M, N), device=dev(), dtype=torch.float32)
+    ops.gemm(g32(a), M, g32(b), N, out, N, M, N, K, flags=ops.GEMM_A_KMAJOR | ops.GEMM_B_KMAJOR | ops.GEMM_SPLITK)
+    assert rel_l2(out.cpu(), a.T @ b) < 5e-6
+    out2 = torch.empty((M, N), device=dev(), dtype=torch.float32)
+    ops.gemm(g32(a), M, g32(b), N, out2, N, M, N, K, flags=ops.GEMM_A_KMAJOR | ops.GEMM_B_KMAJOR)
+    assert rel_l2(out2.cpu(), a.T @ b) < 5e-6
+
+
 def test_gemm_splitk_large_k():
     from transvae_amd import ops
     M, N, K = 20000, 160, 96          # wgrad shape: reduction over 20000 rows

@@ -112,7 +112,7 @@ def test_sample_script_slab_decode_equals_per_batch_loop(tmp_path, monkeypatch, 
         argv = ["--model", "transvae", "--model_ckpt", "slab.ckpt", "--sample_mode", mode, "--n_samples", "230",
                 "--n_samples_per_batch", "25", "--save_path", "gen%s.csv" % per_batch]
         if mode != "rand":
-            argv += ["--mols", "mols.txt", "--entropy_cutoff", "-1e9", "--k", "7"]
+            argv += ["--mols", "mols.txt", "--entropy_cutoff=-1e9", "--k", "7"]
         sample.sample(parsers.sample_parser().parse_args(argv))
         outs.append(pd.read_csv("gen%s.csv" % per_batch, keep_default_na=False)["mol"].tolist())
     assert len(outs[0]) == 250 and outs[0] == outs[1]

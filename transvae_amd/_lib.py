@@ -41,6 +41,7 @@ SIGNATURES = {
     "tvae_embed_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _u, _f, _vp],
     "tvae_conv_w_pack": [_vp, _vp, _i, _i, _i, _i, _vp],
     "tvae_conv_w_unpack_grad": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "tvae_deconv_poly_pack": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "tvae_pool_relu_fwd": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "tvae_pool_relu_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "tvae_upsample_fwd": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp],

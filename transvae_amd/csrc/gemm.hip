@@ -465,8 +465,15 @@ int tile_depth(bool bf16, int tiles, bool splitk, bool drop) {
 void tvae_gemm3_launch(const void* gp, int tiles, int splits, bool a_km, bool b_km, bool drop, bool b_split,
                        hipStream_t s);   // gemm3.hip
 void tvae_gemm_dma_launch(const void* gp, bool bf16, hipStream_t s);   // gemm_dma.hip
+void tvae_gemm_wide_launch(const void* gp, int splits, bool km, hipStream_t s);   // gemm_wide.hip
 
 namespace {
+// TVAE_GEMM_WIDE: 0 never use the 128 x 160 kernel, 1 (default) for N in (128, 160], 2 for every N that wastes fewer columns on
+// 160-wide tiles than on 128-wide ones (experiment switch; read once)
+int wide_mode() {
+  static int m = [] { const char* e = getenv("TVAE_GEMM_WIDE"); return e ? atoi(e) : 1; }();
+  return m;
+}
 bool fp32_dma_enabled() {   // TVAE_GEMM_DMA=1: exact-fp32 NT products take the LDS-DMA kernel too (experiment switch; read once)
   static bool on = [] { const char* e = getenv("TVAE_GEMM_DMA"); return e && atoi(e) == 1; }();
   return on;
@@ -545,6 +552,30 @@ static int gemm_impl(const float* A, int lda, const float* B, int ldb, float* C,
     tvae_gemm_dma_launch(&g, b_bf16, (hipStream_t)stream);
     TVAE_LAUNCH_CHECK("tvae_gemm");
     return TVAE_OK;
+  }
+  // wide-tile kernel (gemm_wide.hip): exact fp32, N just above a multiple of 128 (the conv bottleneck's 148 / 160 channels), both
+  // operands in the same orientation, nothing fused beyond alpha / bias / ReLU / split-K.  In f32x3 mode too for N <= 160: the
+  // 3xbf16 kernel on a 58-62 % full tile pair is no faster than exact fp32 on a full tile.
+  {
+    const int wm = wide_mode();
+    const bool wide_n = wm >= 1 && N > 128 && (N <= 160 || (wm >= 2 && dtype == TVAE_F32 && cdiv(N, 160) * 160 < cdiv(N, 128) * 128));
+    const int other = flags & ~(TVAE_GEMM_RELU | TVAE_GEMM_SPLITK | TVAE_GEMM_A_KMAJOR | TVAE_GEMM_B_KMAJOR | FLAG_VEC_EPILOGUE | FLAG_FAST_STAGE);
+    if (wide_n && batch == 1 && !bf16 && a_km == b_km && other == 0 && !residual && !a_rowsum && !drop && K >= 256 &&
+        (g.flags & FLAG_FAST_STAGE)) {
+      int splits = 1;
+      g.k_per_split = K;
+      if (flags & TVAE_GEMM_SPLITK) {
+        const int wtiles = cdiv(M, 128) * cdiv(N, 160), ktiles = cdiv(K, 32);
+        splits = 768 / wtiles;                       // one round of resident workgroups: 256 CUs x 3
+        if (splits > ktiles / 8) splits = ktiles / 8;
+        if (splits < 1) splits = 1;
+        g.k_per_split = cdiv(ktiles, splits) * 32;
+        splits = cdiv(K, g.k_per_split);
+      }
+      tvae_gemm_wide_launch(&g, splits, a_km, (hipStream_t)stream);
+      TVAE_LAUNCH_CHECK("tvae_gemm");
+      return TVAE_OK;
+    }
   }
   const int BK = x3 ? 32 : tile_depth(bf16, tiles, flags & TVAE_GEMM_SPLITK, drop);
   int splits = 1;

@@ -236,9 +236,59 @@ __global__ void conv_w_pack_kernel(const float* __restrict__ w, float* __restric
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
     int co = i / (k * Cin), rem = i % (k * Cin), j = rem / Cin, ci = rem % Cin;
     size_t src = tf ? ((size_t)ci * Cout + co) * k + (k - 1 - j) : ((size_t)co * Cin + ci) * k + j;
-    if (unpack_grad) wp[src] = w[i];   // here `w` is dwp (packed layout) and `wp` is dw
+    if (unpack_grad == 2) wp[src] = w[(size_t)rem * Cout + co];   // dwp arrives TRANSPOSED, (k*Cin, Cout)
+    else if (unpack_grad) wp[src] = w[i];   // here `w` is dwp (packed layout) and `wp` is dw
     else wp[i] = w[src];
   }
+}
+
+// ---- ConvTranspose1d as a POLYPHASE product (no zero-stuffed input) ----------------------------------------------
+// out[b, co, t] = sum_{ci, i, j : t + pad = i s + j} x[b, ci, i] w[ci, co, j].  With t + pad = m s + r (r < s) only the
+// taps j = r + s q (q < Q = ceil(k / s)) reach phase r, from inputs i = m - q: per phase a Q-tap convolution of the
+// UN-upsampled input, and all s phases together ONE product
+//   C[(b, m), (r, co)] = sum_{qq < Q, ci} xp[(b, m + qq), ci] . wp[(r, co), (qq, ci)]
+// over the input padded with Q - 1 leading zero rows per molecule (window row qq holds input i = m - (Q - 1 - qq)), whose
+// output rows (b, m) x (r, co) ARE the token-major rows (b, m s + r) x co.  FLOPs = those of the transposed convolution
+// itself (x s / k less than the zero-stuffed form).  Modes:
+//   0  wp (s Cout, Q Cin):   wp[(r, co), (qq, ci)] = w[ci, co, r + s (Q - 1 - qq)]   (0 where that tap is >= k); bias tiled s times
+//   1  wd (Cin, Q s Cout):   wd[ci, (q, r, co)]    = w[ci, co, r + s q]              the data-gradient product's weight
+//   2  dw (Cin, Cout, k) from dwp laid out as mode 0, db[co] = sum_r dbp[(r, co)]
+__global__ void deconv_poly_pack_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ bin,
+                                        float* __restrict__ bout, int Cin, int Cout, int k, int s, int Q, int mode) {
+  const int gtid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
+  if (mode == 2) {
+    const int total = Cin * Cout * k;
+    for (int i = gtid; i < total; i += gsz) {
+      const int j = i % k, co = (i / k) % Cout, ci = i / (k * Cout);
+      const int r = j % s, qq = Q - 1 - j / s;
+      out[i] = in[((size_t)r * Cout + co) * (Q * Cin) + qq * Cin + ci];
+    }
+    if (bin && bout)
+      for (int co = gtid; co < Cout; co += gsz) {
+        float t = 0.f;
+        for (int r = 0; r < s; ++r) t += bin[r * Cout + co];
+        bout[co] = t;
+      }
+    return;
+  }
+  const int total = s * Cout * Q * Cin;
+  for (int i = gtid; i < total; i += gsz) {
+    int ci, co, j;
+    if (mode == 0) {
+      ci = i % Cin;
+      const int qq = (i / Cin) % Q, rc = i / (Cin * Q);
+      co = rc % Cout;
+      j = rc / Cout + s * (Q - 1 - qq);
+    } else {
+      co = i % Cout;
+      const int qr = (i / Cout) % (Q * s);        // q s + r = the tap itself
+      ci = i / (Cout * Q * s);
+      j = qr;
+    }
+    out[i] = j < k ? in[((size_t)ci * Cout + co) * k + j] : 0.f;
+  }
+  if (mode == 0 && bin && bout)
+    for (int i = gtid; i < s * Cout; i += gsz) bout[i] = bin[i % Cout];
 }
 
 __global__ __launch_bounds__(256) void pool_relu_fwd_kernel(const float* __restrict__ conv, float* __restrict__ y,
@@ -500,8 +550,20 @@ extern "C" int tvae_conv_w_unpack_grad(const float* dwp, float* dw, int Cout, in
                                        void* stream) {
   TVAE_CHECK(dwp && dw && Cout > 0 && Cin > 0 && k > 0, TVAE_E_SHAPE, "tvae_conv_w_unpack_grad: bad arguments");
   hipLaunchKernelGGL(conv_w_pack_kernel, dim3(grid_for((size_t)Cout * Cin * k)), dim3(256), 0, (hipStream_t)stream, dwp,
-                     dw, Cout, Cin, k, transposed_flip, 1);
+                     dw, Cout, Cin, k, transposed_flip & 1, (transposed_flip & 2) ? 2 : 1);
   TVAE_LAUNCH_CHECK("tvae_conv_w_unpack_grad");
+  return TVAE_OK;
+}
+
+extern "C" int tvae_deconv_poly_pack(const float* in, float* out, const float* bias_in, float* bias_out, int Cin, int Cout,
+                                     int k, int stride, int mode, void* stream) {
+  TVAE_CHECK(in && out, TVAE_E_NULL, "tvae_deconv_poly_pack: null pointer");
+  TVAE_CHECK(Cin > 0 && Cout > 0 && k > 0 && stride >= 1 && mode >= 0 && mode <= 2, TVAE_E_SHAPE,
+             "tvae_deconv_poly_pack: bad arguments (Cin %d Cout %d k %d stride %d mode %d)", Cin, Cout, k, stride, mode);
+  const int Q = (k + stride - 1) / stride;
+  hipLaunchKernelGGL(deconv_poly_pack_kernel, dim3(grid_for((size_t)stride * Cout * Q * Cin)), dim3(256), 0, (hipStream_t)stream,
+                     in, out, bias_in, bias_out, Cin, Cout, k, stride, Q, mode);
+  TVAE_LAUNCH_CHECK("tvae_deconv_poly_pack");
   return TVAE_OK;
 }
 

@@ -801,9 +801,9 @@ def _pack_w(w, rows, inner, k, tf):
     return wp
 
 
-def _unpack_dw(dwp, shape, Cout, Cin, k, tf):
+def _unpack_dw(dwp, shape, Cout, Cin, k, tf, transposed=False):
     dw = torch.empty(shape, device=dwp.device, dtype=torch.float32)
-    call("tvae_conv_w_unpack_grad", _p(dwp), _p(dw), Cout, Cin, k, int(tf), _stream())
+    call("tvae_conv_w_unpack_grad", _p(dwp), _p(dw), Cout, Cin, k, int(tf) | (2 if transposed else 0), _stream())
     return dw
 
 
@@ -818,12 +818,20 @@ def _conv_gemm(xin, rows_total, Cin, wp, bias, k, relu):
 
 
 def _conv_wgrad(dy_rows, xin, rows_total, Cin, Cout, k):
-    """dwp[co, j*Cin+ci] = sum_r dy[r, co] x[r+j, ci] over r < rows_total-(k-1) (split-K atomics)."""
+    """dwp[co, j*Cin+ci] = sum_r dy[r, co] x[r+j, ci] over r < rows_total-(k-1) (split-K atomics).  Returns
+    (dwp, db, transposed): with 128 < Cout <= 160 the operands are swapped -- dwp comes out as (k*Cin, Cout), so that
+    Cout lies along N on tvae_gemm's 160-wide tile instead of along M on two 128-row tiles, the second a quarter full."""
+    rows = rows_total - (k - 1)
+    dt = _role_dtype("wgrad")
+    if 128 < Cout <= 160 and dt != BF16 and Cin % 4 == 0 and Cout % 4 == 0:
+        dwt = torch.zeros((k * Cin, Cout), device=xin.device, dtype=torch.float32)
+        gemm(xin, Cin, dy_rows, Cout, dwt, Cout, k * Cin, Cout, rows, flags=GEMM_A_KMAJOR | GEMM_B_KMAJOR | GEMM_SPLITK, dtype=dt)
+        return dwt, colsum(dy_rows[:rows]), True
     dwp = torch.zeros((Cout, k * Cin), device=xin.device, dtype=torch.float32)
     db = torch.zeros((Cout,), device=xin.device, dtype=torch.float32)     # bias grad, fused row sums
-    gemm(dy_rows, Cout, xin, Cin, dwp, k * Cin, Cout, k * Cin, rows_total - (k - 1),
-         flags=GEMM_A_KMAJOR | GEMM_B_KMAJOR | GEMM_SPLITK, a_rowsum=db, dtype=_role_dtype("wgrad"))
-    return dwp, db
+    gemm(dy_rows, Cout, xin, Cin, dwp, k * Cin, Cout, k * Cin, rows,
+         flags=GEMM_A_KMAJOR | GEMM_B_KMAJOR | GEMM_SPLITK, a_rowsum=db, dtype=dt)
+    return dwp, db, False
 
 
 def _conv_dgrad(dy_padded, rows_total, Cout, w_dgrad, Cin, k):
@@ -873,8 +881,8 @@ class ConvBottleneckFn(torch.autograd.Function):
             buf = torch.zeros(((k - 1) + B * L, Cout), device=dy.device, dtype=torch.float32)
             dconv = buf[k - 1:]
             call("tvae_pool_relu_bwd", _p(conv), _p(dy), _p(dconv), B, L, Lconv, Cout, int(li == 2), _stream())
-            dwp, grads[2 * li + 1] = _conv_wgrad(dconv, xin, B * L, Cin, Cout, k)
-            grads[2 * li] = _unpack_dw(dwp, W[li].shape, Cout, Cin, k, False)
+            dwp, grads[2 * li + 1], tr = _conv_wgrad(dconv, xin, B * L, Cin, Cout, k)
+            grads[2 * li] = _unpack_dw(dwp, W[li].shape, Cout, Cin, k, False, tr)
             if li > 0 or ctx.needs_input_grad[0]:
                 wd = _pack_w(W[li], Cin, Cout, k, True)       # (Cin, k*Cout): wd[ci][j*Cout+co] = W[co][ci][k-1-j]
                 dy = _conv_dgrad(buf, B * L, Cout, wd, Cin, k)
@@ -882,9 +890,25 @@ class ConvBottleneckFn(torch.autograd.Function):
         return (dx,) + tuple(grads)
 
 
+def _poly_pack(W, b, s, mode):
+    """GEMM weight (and bias) of the polyphase form of a strided ConvTranspose1d, see tvae_deconv_poly_pack."""
+    Cin, Cout, k = W.shape
+    Q = -(-k // s)
+    shape = (s * Cout, Q * Cin) if mode == 0 else (Cin, Q * s * Cout)
+    wp = torch.empty(shape, device=W.device, dtype=torch.float32)
+    bp = torch.empty((s * Cout,), device=W.device, dtype=torch.float32) if (mode == 0 and b is not None) else None
+    call("tvae_deconv_poly_pack", _p(W), _p(wp), _p(b if bp is not None else None), _p(bp), Cin, Cout, k, s, mode, _stream())
+    return wp, bp
+
+
 class DeconvBottleneckFn(torch.autograd.Function):
     """DeconvBottleneck (trans_models.py:1001-1009): 3 x relu(ConvTranspose1d(k=11, stride, pad 2)).
-    Input (B, 576) = the (B,64,9) view of relu(decoder.linear(z)) (:852-853); output (B, 127, d)."""
+    Input (B, 576) = the (B,64,9) view of relu(decoder.linear(z)) (:852-853); output (B, 127, d).
+
+    Strided layers (4, 3) run as POLYPHASE products over the un-upsampled input (include/tvae_kernels.h,
+    tvae_deconv_poly_pack): one GEMM with K = ceil(k/s) Cin and N = s Cout whose output rows are the token-major output --
+    the FLOPs of the transposed convolution itself, where the zero-stuffed form (still used for stride 1, where it stuffs
+    nothing) multiplied s - 1 zero rows out of every s.  TVAE_DECONV_POLY=0 restores the zero-stuffed form everywhere."""
     STRIDES = (4, 3, 1)
     PAD = 2
 
@@ -895,19 +919,37 @@ class DeconvBottleneckFn(torch.autograd.Function):
         _chk(src, "hlin")
         Lin, src_rows, src_cm = hlin.shape[1] // W0.shape[0], 0, 1
         saved, metas = [], []
+        poly_on = os.environ.get("TVAE_DECONV_POLY", "1") == "1"
+        PAD = DeconvBottleneckFn.PAD
         for li, (W, b) in enumerate(((W0, b0), (W1, b1), (W2, b2))):
             Cin, Cout, k = W.shape
-            s, lpad = DeconvBottleneckFn.STRIDES[li], k - 1 - DeconvBottleneckFn.PAD
-            Lout = (Lin - 1) * s - 2 * DeconvBottleneckFn.PAD + k
-            Lup = Lout + k - 1
-            up = torch.empty((B * Lup, Cin), device=src.device, dtype=torch.float32)
-            call("tvae_upsample_fwd", _p(src), src_rows, src_cm, _p(up), B, Lin, Cin, s, lpad, Lup, _stream())
-            wp = _pack_w(W, Cout, Cin, k, True)                          # flipped taps, (Cout, k*Cin)
-            y = _conv_gemm(up, B * Lup, Cin, wp, b, k, relu=True)        # (B*Lup, Cout), rows t < Lout valid
-            saved += [up, y]
-            metas.append((Lin, Lout, Lup, Cin, Cout, k, s, lpad))
-            src, Lin, src_rows, src_cm = y, Lout, Lup, 0
-        Cd = metas[2][4]
+            s = DeconvBottleneckFn.STRIDES[li]
+            Lout = (Lin - 1) * s - 2 * PAD + k
+            if poly_on and s > 1 and PAD < s:
+                # rows per molecule: Lm phase groups m (output position t = m s + r - PAD), Q - 1 zero rows in front
+                Q = -(-k // s)
+                Lm = ((Lin - 1) * s - PAD + k - 1) // s + 1
+                Lp = Lm + Q - 1
+                xp = torch.empty((B * Lp, Cin), device=src.device, dtype=torch.float32)
+                call("tvae_upsample_fwd", _p(src), src_rows, src_cm, _p(xp), B, Lin, Cin, 1, Q - 1, Lp, _stream())
+                wp, bp = _poly_pack(W, b, s, 0)
+                y = torch.empty((B * Lp * s, Cout), device=src.device, dtype=torch.float32)      # = (B*Lp, s*Cout)
+                gemm(xp, Cin, wp, Q * Cin, y, s * Cout, B * Lp - (Q - 1), s * Cout, Q * Cin, bias=bp, flags=GEMM_RELU)
+                saved += [xp, y]
+                metas.append(("poly", Lin, Lout, Lp, Cin, Cout, k, s, Q))
+                src, src_rows, src_cm = y[PAD:], Lp * s, 0           # output position t of molecule b: row b Lp s + PAD + t
+            else:
+                lpad = k - 1 - PAD
+                Lup = Lout + k - 1
+                up = torch.empty((B * Lup, Cin), device=src.device, dtype=torch.float32)
+                call("tvae_upsample_fwd", _p(src), src_rows, src_cm, _p(up), B, Lin, Cin, s, lpad, Lup, _stream())
+                wp = _pack_w(W, Cout, Cin, k, True)                          # flipped taps, (Cout, k*Cin)
+                y = _conv_gemm(up, B * Lup, Cin, wp, b, k, relu=True)        # (B*Lup, Cout), rows t < Lout valid
+                saved += [up, y]
+                metas.append(("up", Lin, Lout, Lup, Cin, Cout, k, s, lpad))
+                src, src_rows, src_cm = y, Lup, 0
+            Lin = Lout
+        Cd = metas[2][5]
         out = torch.empty((B, Lin, Cd), device=src.device, dtype=torch.float32)
         call("tvae_upsample_fwd", _p(src), src_rows, 0, _p(out), B, Lin, Cd, 1, 0, Lin, _stream())
         ctx.save_for_backward(W0, W1, W2, *saved)
@@ -919,27 +961,51 @@ class DeconvBottleneckFn(torch.autograd.Function):
         W = ctx.saved_tensors[:3]
         saved = ctx.saved_tensors[3:]
         B = ctx.B
+        PAD = DeconvBottleneckFn.PAD
         grads = [None] * 6
         # (dup, d_stride, d_lpad, d_Lup): where the gradient of layer li's OUTPUT rows lives
-        dup, d_stride, d_lpad, d_Lup = _c(dout), 1, 0, ctx.metas[2][1]
+        dup, d_stride, d_lpad, d_Lup = _c(dout), 1, 0, ctx.metas[2][2]
         for li in (2, 1, 0):
-            Lin, Lout, Lup, Cin, Cout, k, s, lpad = ctx.metas[li]
-            up, y = saved[2 * li], saved[2 * li + 1]
-            buf = torch.zeros(((k - 1) + B * Lup, Cout), device=dup.device, dtype=torch.float32)
-            dyr = buf[k - 1:]
-            call("tvae_upsample_bwd", _p(dup), _p(y), _p(dyr), Lup, 0, B, Lout, Cout, d_stride, d_lpad, d_Lup,
-                 _stream())
-            dwp, grads[2 * li + 1] = _conv_wgrad(dyr, up, B * Lup, Cin, Cout, k)
-            grads[2 * li] = _unpack_dw(dwp, W[li].shape, Cout, Cin, k, True)
-            if li > 0 or ctx.needs_input_grad[0]:
-                wd = _pack_w(W[li], Cin, Cout, k, False)                 # wd[ci][j*Cout+co] = W[ci][co][j]
-                dup = _conv_dgrad(buf, B * Lup, Cout, wd, Cin, k)        # gradient of the zero-stuffed input
-                d_stride, d_lpad, d_Lup = s, lpad, Lup
+            kind, Lin, Lout = ctx.metas[li][:3]
+            xin, y = saved[2 * li], saved[2 * li + 1]
+            if kind == "poly":
+                _, _, _, Lp, Cin, Cout, k, s, Q = ctx.metas[li]
+                # gradient of the pre-activation in the product's own layout (B*Lp, s*Cout) = rows (b, m s + r) x co:
+                # masked by the ReLU, zero on the rows outside [PAD, PAD + Lout) of every molecule
+                buf = torch.zeros((B * Lp * s + PAD, Cout), device=dup.device, dtype=torch.float32)
+                call("tvae_upsample_bwd", _p(dup), _p(y[PAD:]), _p(buf[PAD:]), Lp * s, 0, B, Lout, Cout, d_stride, d_lpad,
+                     d_Lup, _stream())
+                rows = B * Lp - (Q - 1)
+                dwp = torch.zeros((s * Cout, Q * Cin), device=dup.device, dtype=torch.float32)
+                dbp = torch.zeros((s * Cout,), device=dup.device, dtype=torch.float32)
+                gemm(buf, s * Cout, xin, Cin, dwp, Q * Cin, s * Cout, Q * Cin, rows,
+                     flags=GEMM_A_KMAJOR | GEMM_B_KMAJOR | GEMM_SPLITK, a_rowsum=dbp, dtype=_role_dtype("wgrad"))
+                dW = torch.empty_like(W[li])
+                db = torch.empty((Cout,), device=dup.device, dtype=torch.float32)
+                call("tvae_deconv_poly_pack", _p(dwp), _p(dW), _p(dbp), _p(db), Cin, Cout, k, s, 2, _stream())
+                grads[2 * li], grads[2 * li + 1] = dW, db
+                if li > 0 or ctx.needs_input_grad[0]:
+                    wd, _ = _poly_pack(W[li], None, s, 1)                    # (Cin, Q*s*Cout)
+                    dx = torch.empty((B * Lp, Cin), device=dup.device, dtype=torch.float32)
+                    gemm(buf, s * Cout, wd, Q * s * Cout, dx, Cin, rows, Cin, Q * s * Cout, dtype=_role_dtype("dgrad"))
+                    dup, d_stride, d_lpad, d_Lup = dx, 1, 0, Lp              # input i of molecule b: row b Lp + i
+            else:
+                _, _, _, Lup, Cin, Cout, k, s, lpad = ctx.metas[li]
+                buf = torch.zeros(((k - 1) + B * Lup, Cout), device=dup.device, dtype=torch.float32)
+                dyr = buf[k - 1:]
+                call("tvae_upsample_bwd", _p(dup), _p(y), _p(dyr), Lup, 0, B, Lout, Cout, d_stride, d_lpad, d_Lup,
+                     _stream())
+                dwp, grads[2 * li + 1], tr = _conv_wgrad(dyr, xin, B * Lup, Cin, Cout, k)
+                grads[2 * li] = _unpack_dw(dwp, W[li].shape, Cout, Cin, k, True, tr)
+                if li > 0 or ctx.needs_input_grad[0]:
+                    wd = _pack_w(W[li], Cin, Cout, k, False)                 # wd[ci][j*Cout+co] = W[ci][co][j]
+                    dup = _conv_dgrad(buf, B * Lup, Cout, wd, Cin, k)        # gradient of the zero-stuffed input
+                    d_stride, d_lpad, d_Lup = s, lpad, Lup
         dh = None
         if ctx.needs_input_grad[0]:
-            Lin, Lout, Lup, Cin, Cout, k, s, lpad = ctx.metas[0]
+            Lin, Cin = ctx.metas[0][1], ctx.metas[0][4]
             dh = torch.empty((B, Cin * Lin), device=dup.device, dtype=torch.float32)
-            call("tvae_upsample_bwd", _p(dup), None, _p(dh), Lin, 1, B, Lin, Cin, s, lpad, Lup, _stream())
+            call("tvae_upsample_bwd", _p(dup), None, _p(dh), Lin, 1, B, Lin, Cin, d_stride, d_lpad, d_Lup, _stream())
         return (dh,) + tuple(grads)
 
 

@@ -80,18 +80,20 @@ def roofline_of(mode, M, N, K):
     ach = flops / tg / 1e12
     # HBM bytes per launch of this kernel and shape, from separate rocprofv3 --pmc passes
     # (tools/pmc_traffic.sh -> profiles/r<round>_gemm_pmc_<mode>.json); None when no such measurement exists
-    traffic = None
-    for tag in ("r2", "r1"):              # the newest measurement of this kernel and shape
+    traffic, traffic_source = None, None
+    for tag in ("r3", "r2", "r1"):        # the newest measurement of this kernel and shape
         pmc = os.path.join(ROOT, "profiles", "%s_gemm_pmc_%s.json" % (tag, mode))
         if os.path.exists(pmc):
             rec = json.load(open(pmc))
             if rec.get("shape") == [M, N, K]:
                 traffic = rec["traffic_bytes_per_launch"]
+                traffic_source = ("profiles/%s_gemm_pmc_%s.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this "
+                                  "kernel and shape (tools/pmc_traffic.sh), not measured in this run" % (tag, mode))
                 break
     kern = {"fp32": "gemm_kernel (v_mfma_f32_32x32x2_f32)", "bf16": "gemm_dma_kernel (v_mfma_f32_32x32x16_bf16; fp32 activations and bf16 weights streamed to LDS by LDS-DMA)",
             "f32x3": "gemm3_kernel (6 x v_mfma_f32_32x32x16_bf16 per fp32 product block; peak = bf16 peak / 6)"}[mode]
     return {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[mode], "unit": "TFLOP/s",
-            "frac": ach / PEAK_TFLOPS[mode], "traffic": traffic,
+            "frac": ach / PEAK_TFLOPS[mode], "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_bytes": 4.0 * (M * K + N * K + N + M * N),
             "kernel": "%s: x[%d,%d] @ W[%d,%d]^T + bias, ReLU" % (kern, M, K, N, K),
             "launch_us": tg * 1e6, "flop_per_launch": flops}
@@ -120,16 +122,101 @@ def roofline_decode_of(n):
     "roofline object of decode_attn_kernel (HBM-bound), timed live with events on the launch stream"
     fn, nbytes = decode_attn_launch(n)
     t = time_launches(fn, 20)
-    traffic = None
+    traffic, traffic_source = None, None
     pmc = os.path.join(ROOT, "profiles", "r2_decode_attn_pmc.json")
     if os.path.exists(pmc):
         rec = json.load(open(pmc))
         if rec.get("shape", {}).get("n") == n:
             traffic = rec["traffic_bytes_per_launch"]
+            traffic_source = "profiles/r2_decode_attn_pmc.json (rocprofv3 --pmc passes, tools/pmc_decode.sh; the kernel is unchanged since), not measured in this run"
     return {"bound": "hbm", "achieved": nbytes / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / t / 1e9 / 8000.0,
-            "traffic": traffic, "algorithmic_bytes": nbytes, "launch_us": t * 1e6,
+            "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes": nbytes, "launch_us": t * 1e6,
             "kernel": "decode_attn_kernel<64>: one query per (molecule, head) over 63 cached fp32 K and V rows, %d molecules "
                       "(half of the decode's device time; the other half is the fp32 MFMA GEMMs of `roofline`)" % n}
+
+
+def _live_tile_fraction(key_mask, Lq, causal):
+    """Fraction of the (32-query block, 32-key tile) pairs of an attention call that the kernels execute: a pair whose mask
+    words are all zero is skipped (it only produces exact zeros), csrc/attention.hip.  key_mask (B, Lk) bool on the host."""
+    B, Lk = key_mask.shape
+    nq, nk = (Lq + 31) // 32, (Lk + 31) // 32
+    live = 0
+    vis = key_mask.bool()
+    for kt in range(nk):
+        any_key = vis[:, 32 * kt:32 * kt + 32].any(1)                      # (B,)
+        for qb in range(nq):
+            if causal and 32 * kt > min(32 * qb + 31, Lq - 1):             # the whole tile lies above the diagonal
+                continue
+            live += int(any_key.sum())
+    return live / float(B * nq * nk)
+
+
+def roofline_attention_of(batch, h=4, dk=64, iters=20):
+    """Roofline object of the fused attention kernels (csrc/attention.hip) on the encoder self-attention shape of the
+    train step (127 x 127 per molecule and head, 4 of the 10 attention blocks; the other 6 are 126 x 126 / 126 x 127), on
+    the SMILES-shaped batch the step runs on and on a batch without padding.  FLOPs: dense count 4 Lq Lk d per molecule
+    forward (QK^T and PV), 2.5 x that backward (S recomputed, dP, dV, dQ, dK) -- SURVEY.md 8(d) -- and the LIVE-tile count
+    (the tiles the kernels execute; all-masked tiles are skipped because they are exact zeros).  Bytes: Q, K, V in and O
+    out (forward), Q, K, V, O, dO in and dQ, dK, dV out (backward), fp32 rows of the surrounding GEMMs."""
+    from transvae_amd import ops, synth
+    B, d, Lq, Lk = batch, h * dk, 127, 127
+    dev = torch.device("cuda", torch.cuda.current_device())
+    toks = synth.synth_tokens(B, seed=100)
+    drop = ops.Drop(0.1, 3, ops.rng_state(dev))
+    dense_f = 4.0 * Lq * Lk * d * B
+    out = {"bound": "mfma", "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s", "hbm_peak_GBps": 8000.0,
+           "shape": "encoder self-attention of the train step: B %d, h %d, Lq = Lk = 127, dk %d, dropout 0.1 on P" % (B, h, dk),
+           "kernels": {}}
+    for pad in ("smiles", "unpadded"):
+        km = (toks[:, :Lk] != 24) if pad == "smiles" else torch.ones(B, Lk, dtype=torch.bool)
+        spec = ops.MaskSpec(key_mask=km.to(torch.uint8).to(dev), causal=False)
+        q, k, v, do = (torch.randn(B * L, d, device=dev) for L in (Lq, Lk, Lk, Lq))
+        o, lse, _ = ops.attn_fwd(q, k, v, B, h, Lq, Lk, dk, spec, drop)
+        tf = time_launches(lambda: ops.attn_fwd(q, k, v, B, h, Lq, Lk, dk, spec, drop), iters, 0.1)
+        tb = time_launches(lambda: ops.attn_bwd(q, k, v, o, do, lse, B, h, Lq, Lk, dk, spec, drop), iters, 0.1)
+        live = _live_tile_fraction(km, Lq, False)
+        row_bytes = 4.0 * B * Lq * d
+        for name, t, fl, nbytes in (("attn_fwd_kernel<64>", tf, dense_f, 4 * row_bytes),
+                                    ("attn_bwd_dq_kernel<64> + attn_bwd_dkv_kernel<64>", tb, 2.5 * dense_f, 8 * row_bytes)):
+            out["kernels"].setdefault(name, {})[pad] = {
+                "launch_us": t * 1e6, "mean_visible_keys": float(km.float().sum(1).mean()),
+                "dense_flop": fl, "live_tile_fraction": live, "achieved_dense_tflops": fl / t / 1e12,
+                "achieved_live_tflops": fl * live / t / 1e12, "frac_of_mfma_peak_live": fl * live / t / 1e12 / PEAK_TFLOPS["fp32"],
+                "algorithmic_bytes": nbytes, "achieved_GBps": nbytes / t / 1e9, "frac_of_hbm_peak": nbytes / t / 1e9 / 8000.0}
+    bw = out["kernels"]["attn_bwd_dq_kernel<64> + attn_bwd_dkv_kernel<64>"]
+    out["achieved"] = bw["unpadded"]["achieved_dense_tflops"]        # headline: the backward pair with every tile live
+    out["frac"] = out["achieved"] / PEAK_TFLOPS["fp32"]
+    out["traffic"] = None
+    out["counters"] = "profiles/r3_attn_sq_counters.txt (rocprofv3 --pmc over tools/attn_bench.py: MFMA-busy, LDS bank conflicts, wave stalls)"
+    return out
+
+
+def config1_of(steps, cpu_threads=None):
+    """BASELINE.json configs[0]: trans1x-128, one fp32 train step (forward + loss + backward + Noam/Adam) on a synthetic
+    batch of 500 -- on the GPU (the same one-pass step as the headline model) and, if cpu_threads, the CPU oracle beside it."""
+    from transvae_amd import ops, synth
+    ops.set_compute_dtype("fp32")
+    vae = build_vae("trans1x-128")
+    vae.model.train()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    toks = synth.synth_tokens(500, seed=100)
+    data = torch.cat([toks.float(), torch.zeros(500, 1)], 1).to(dev)
+    for _ in range(3):
+        vae.train_step(data, 0.01)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        vae.train_step(data, 0.01)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out = {"workload": "trans1x-128 ZINC-vocab train step (fwd+loss+bwd+Noam/Adam), batch 500 in one pass (5 x 100 chunk-wise loss "
+                       "normalisation), dropout 0.1, fp32, synthetic SMILES-shaped tokens, synthetic checkpoint",
+           "value": 500 * 126 / dt, "unit": "tokens/s", "ms_per_step": 1e3 * dt, "steps": steps, "dtype": "f32",
+           "train_algorithmic_tflops": 500 * 1.141e9 / dt / 1e12}
+    del vae
+    if cpu_threads:
+        out["cpu_baseline"] = cpu_baseline(cpu_threads, arch="trans1x-128", cfg="1x128_zinc", d_model=128)
+    return out
 
 
 def rnn_secondary(kind, d_model, batch=500, steps=5, decode_n=16384):
@@ -163,17 +250,24 @@ def rnn_secondary(kind, d_model, batch=500, steps=5, decode_n=16384):
             "batch": batch, "decode_mols_per_s": decode_n / td, "decode_batch": decode_n}
 
 
-def cpu_baseline(threads, batch=500, chunks=5):
+def host_threads():
+    """Threads for the CPU baseline: this process's CPU share.  On the GPU box os.cpu_count() is the whole 8-GPU host; the
+    share of one GPU's job is what OMP_NUM_THREADS says there (16), so that is used when set, else every core."""
+    env = os.environ.get("OMP_NUM_THREADS", "")
+    return int(env) if env.isdigit() and int(env) > 0 else (os.cpu_count() or 1)
+
+
+def cpu_baseline(threads, batch=500, chunks=5, arch="trans4x-256", cfg="4x256_zinc", d_model=256, n_timed=3):
     """The oracle's train step on host cores, as SURVEY.md 8(d) asks: batch 500 = 5 chunks of 100 molecules, each
     chunk forward + loss + backward with the gradients accumulating, then one Noam/Adam step.  Two figures: dropout
     on (what scripts/train.py of the reference really runs; `value`) and dropout off.  Bounded sample: one untimed
-    chunk to warm the allocator and the thread pool, then ONE timed step per figure."""
+    chunk to warm the allocator and the thread pool, then n_timed timed steps per figure (median reported, spread kept)."""
     from oracle import tvae_oracle as O
     from transvae_amd import synth
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import oracle_params
     torch.set_num_threads(threads)
-    P = oracle_params("4x256_zinc", torch.float32, requires_grad=True)
+    P = oracle_params(cfg, torch.float32, requires_grad=True)
     keys = [k for k in P if P[k].requires_grad]        # the two positional tables are buffers
     w = torch.tensor(synth.load_vocab("zinc")[2], dtype=torch.float32)
     toks = synth.synth_tokens(batch, seed=1)
@@ -181,8 +275,10 @@ def cpu_baseline(threads, batch=500, chunks=5):
     csize = batch // chunks
     m = [torch.zeros_like(P[k]) for k in keys]
     v = [torch.zeros_like(P[k]) for k in keys]
+    count = [0]
 
-    def step(n, p_drop, n_chunks=chunks):
+    def step(p_drop, n_chunks=chunks):
+        count[0] += 1
         for k in keys:
             P[k].grad = None
         for c in range(n_chunks):
@@ -190,24 +286,31 @@ def cpu_baseline(threads, batch=500, chunks=5):
             losses, _ = O.chunk_loss(P, toks[sl], props[sl], w, 0.01, p_drop=p_drop, attn_drop=p_drop)
             losses[0].backward()                      # accumulates, no 1/chunks (trans_models.py:236)
         with torch.no_grad():
-            O.adam_step([P[k] for k in keys], [P[k].grad for k in keys], m, v, n, O.noam_rate(n, 256))
+            O.adam_step([P[k] for k in keys], [P[k].grad for k in keys], m, v, count[0], O.noam_rate(count[0], d_model))
 
-    step(1, 0.1, n_chunks=1)                          # warm-up: one chunk
-    t0 = time.perf_counter()
-    step(2, 0.1)
-    t_on = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    step(3, 0.0)
-    t_off = time.perf_counter() - t0
+    def timed(p_drop):
+        ts = []
+        for _ in range(n_timed):
+            t0 = time.perf_counter()
+            step(p_drop)
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)
+
+    step(0.1, n_chunks=1)                             # warm-up: one chunk
+    on, off = timed(0.1), timed(0.0)
+    t_on, t_off = on[len(on) // 2], off[len(off) // 2]
     return {"value": batch * 126 / t_on, "unit": "tokens/s", "cores": threads, "kind": "port",
             "value_dropout_off": batch * 126 / t_off,
-            "sample": "one train step of trans4x-256 on %d molecules = %d chunks of %d (forward + loss + backward per chunk, "
-                      "gradients accumulated, then Noam/Adam), fp32 torch CPU oracle on %d threads; 1 warm-up chunk, then 1 "
-                      "timed step with dropout 0.1 as the reference trains (%.1f s; `value`) and 1 with dropout off (%.1f s; "
-                      "`value_dropout_off`)" % (batch, chunks, csize, threads, t_on, t_off)}
+            "step_seconds_dropout_on": on, "step_seconds_dropout_off": off,
+            "host_cpu_count": os.cpu_count(),
+            "sample": "train step of %s on %d molecules = %d chunks of %d (forward + loss + backward per chunk, gradients "
+                      "accumulated, then Noam/Adam), fp32 torch CPU oracle on %d threads (this job's CPU share; the host shows "
+                      "%s); 1 warm-up chunk, then %d timed steps with dropout 0.1 as the reference trains (median %.1f s, range "
+                      "%.1f-%.1f; `value`) and %d with dropout off (median %.1f s; `value_dropout_off`)"
+                      % (arch, batch, chunks, csize, threads, os.cpu_count(), n_timed, t_on, on[0], on[-1], n_timed, t_off)}
 
 
-def cpu_decode_baseline(threads, n=8):
+def cpu_decode_baseline(threads, n=24):
     from oracle import tvae_oracle as O
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import oracle_params
@@ -218,7 +321,7 @@ def cpu_decode_baseline(threads, n=8):
     O.greedy_decode(P, z)
     t = time.perf_counter() - t0
     return {"value": n / t, "unit": "molecules/s", "cores": threads, "kind": "port",
-            "sample": "%d latents, reference-style full-recompute greedy loop, %.1f s" % (n, t)}
+            "sample": "%d latents, reference-style full-recompute greedy loop (trans_models.py:383-436), %.1f s" % (n, t)}
 
 
 def launch_ranks(n):
@@ -262,12 +365,15 @@ def main():
     ap.add_argument("--dtype", choices=["fp32", "f32x3", "bf16"], default="fp32")
     ap.add_argument("--batch", type=int, default=500)
     ap.add_argument("--chunks", type=int, default=5)
-    ap.add_argument("--decode-n", type=int, default=65536)
+    ap.add_argument("--decode-n", type=int, default=1000000,
+                    help="latents to decode IN TOTAL (BASELINE.json config 4: 1 M), sharded over the ranks and decoded in slabs of "
+                         "65,536 per GPU; token ids stay uint8 on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-extra-modes", action="store_true", help="skip the secondary timings in the other GEMM arithmetics")
     ap.add_argument("--no-rnn", action="store_true", help="skip the secondary figures of the recurrent models")
     ap.add_argument("--no-roofline", action="store_true", help="skip the roofline launches (profiles of the train step alone)")
+    ap.add_argument("--no-config1", action="store_true", help="skip the trans1x-128 step (BASELINE.json configs[0])")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run nothing but the launches of the roofline kernel (warmed by time, then 50 timed) and print its roofline "
                          "object: under rocprofv3 --kernel-trace --stats the profile then holds exactly these launches")
@@ -380,6 +486,7 @@ def main():
     last_loss = float(table[:, 0].mean().item())
     tokens = world * args.batch * 126 * args.steps
     value = tokens / dt
+    nonpad = int((toks[:, 1:] != 24).sum())          # target positions that are not padding (rank 0's batch; every rank's has the same length law)
 
     out = {
         "metric": "train tokens/s (fwd+bwd) + decoded mols/s, trans4x-256, 1/2/4/8 MI355X",
@@ -390,8 +497,13 @@ def main():
                                "reference's %d x %d chunk-wise loss normalisation, max_len 126, dropout 0.1, synthetic "
                                "SMILES-shaped tokens, synthetic checkpoint"
                                % (args.batch, args.chunks, args.batch // args.chunks),
+                   "decode_workload": "KV-cached greedy decode of %d latents z ~ N(0, I) in total (BASELINE.json config 4), %d per GPU "
+                                      "in slabs of up to 65,536, token ids kept as uint8 on the device"
+                                      % (args.decode_n, args.decode_n // world),
                    "global_batch": world * args.batch, "seq_len": 126,
                    "parallelism": "dp%d" % world if world > 1 else "single"},
+        "value_nonpad": world * nonpad * args.steps / dt, "nonpad_unit": "non-pad target tokens/s (secondary, SURVEY.md 8d: %d of "
+                        "the %d target positions of a batch carry a token or <end>)" % (nonpad, args.batch * 126),
         "final_loss": last_loss,
         "data_parallel": dp_report,
         "train_algorithmic_tflops": world * args.batch * FLOP_PER_MOL_FWD_BWD * args.steps / dt / 1e12,
@@ -414,43 +526,54 @@ def main():
         ops.set_compute_dtype(args.dtype)
         out["other_gemm_modes"] = others
 
-    # ---- greedy decode (KV-cached), sharded by latent batch: every rank decodes its own slab ------
+    # ---- greedy decode (KV-cached), sharded by latent batch: the --decode-n latents are dealt to the ranks, every rank
+    # decodes its share in slabs of 65,536 (VAEShell.decode_latents), ids stay uint8 on the device; one final gather ------
     if not args.no_decode:
         vae.model.eval()
-        z = torch.randn(args.decode_n, 128, generator=torch.Generator().manual_seed(rank)).to(dev)
+        share = args.decode_n // world + (1 if rank < args.decode_n % world else 0)
+        z = torch.randn(share, 128, generator=torch.Generator().manual_seed(rank)).to(dev)
         vae.greedy_decode(z[:64])
         fence()
         t0 = time.perf_counter()
-        ids = vae.greedy_decode(z)
+        ids = vae.decode_latents(z)
         fence()
         td = time.perf_counter() - t0
         if use_dist:
             td = max_over_ranks(td)
-            small = ids.to(torch.uint8)                                # vocabulary of 26: one byte per token
+            shares = [args.decode_n // world + (1 if r < args.decode_n % world else 0) for r in range(world)]
+            small = torch.zeros((max(shares), ids.shape[1]), dtype=torch.uint8, device=dev)   # vocabulary of 26: one byte per token
+            small[:share] = ids
             if rehearse:
                 small = small.cpu()
             gathered = [torch.empty_like(small) for _ in range(world)] if rank == 0 else None
             dist.gather(small, gathered, dst=0)                        # the one exchange: final token ids
-        out["decode_mols_per_s"] = world * args.decode_n / td
-        out["decode_batch_per_gpu"] = args.decode_n
-        out["decode_algorithmic_tflops"] = world * args.decode_n * FLOP_PER_MOL_DECODE / td / 1e12
+        out["decode_mols_per_s"] = args.decode_n / td
+        out["decode_latents_total"] = args.decode_n
+        out["decode_latents_per_gpu"] = share
+        out["decode_slab"] = min(share, vae.DECODE_SLAB)
+        out["decode_seconds"] = td
+        out["decode_scaling"] = "strong (the total is fixed: BASELINE.json config 4 decodes 1 M latents, sharded by rank)"
+        out["decode_ids_bytes"] = int(ids.numel())                      # uint8 on the device
+        out["decode_algorithmic_tflops"] = args.decode_n * FLOP_PER_MOL_DECODE / td / 1e12
         if not args.no_extra_modes and args.dtype == "fp32":
-            # the same decode with the fp32-accurate 3xbf16 GEMMs (token sequences bit-identical: tests/test_model_gpu.py)
+            # one slab with the fp32-accurate 3xbf16 GEMMs beside the same slab in exact fp32 (two fp32-accurate arithmetics
+            # round differently: among millions of arg-max decisions a few near-ties -- top-2 logit margin below fp32
+            # resolution -- fall the other way and the row diverges from there)
+            n3 = min(share, vae.DECODE_SLAB)
             ops.set_compute_dtype("f32x3")
             vae.greedy_decode(z[:64])
             fence()
             t0 = time.perf_counter()
-            ids3 = vae.greedy_decode(z)
+            ids3 = vae.decode_latents(z[:n3])
             fence()
             t3 = time.perf_counter() - t0
             if use_dist:
                 t3 = max_over_ranks(t3)
             ops.set_compute_dtype(args.dtype)
-            out["decode_other_gemm_modes"] = {"f32x3": {"value": world * args.decode_n / t3, "unit": "molecules/s",
-                                                        # two fp32-accurate arithmetics round differently: among millions of
-                                                        # arg-max decisions a few near-ties (top-2 logit margin below fp32
-                                                        # resolution) fall the other way and the row diverges from there
-                                                        "rows_identical_to_fp32": float((ids3 == ids).all(dim=1).float().mean().item())}}
+            out["decode_other_gemm_modes"] = {"f32x3": {"value": world * n3 / t3, "unit": "molecules/s", "latents_per_gpu": n3,
+                                                        "rows_identical_to_fp32": float((ids3 == ids[:n3]).all(dim=1).float().mean().item())}}
+        del z, ids
+        torch.cuda.empty_cache()                                        # the slab's K/V caches (~110 GB) go back before the rest
 
     if rank == 0:
         # ---- roofline of the dominant kernel: the MFMA GEMM on the FFN w_1 launch shape -----------
@@ -461,8 +584,9 @@ def main():
 
         if not args.no_roofline:
             out["roofline"] = roofline(args.dtype)
+            out["roofline_attention"] = roofline_attention_of(args.batch)
             if not args.no_decode:
-                out["roofline_decode"] = roofline_decode_of(args.decode_n)
+                out["roofline_decode"] = roofline_decode_of(65536)
             if not args.no_extra_modes and args.dtype != "f32x3":
                 out["roofline_f32x3"] = roofline("f32x3")
         ops.set_compute_dtype(args.dtype)
@@ -470,8 +594,11 @@ def main():
             del vae
             torch.cuda.empty_cache()
             out["recurrent_models"] = [rnn_secondary("rnnattn", 256), rnn_secondary("rnn", 128)]
-        if not args.no_cpu_baseline and world == 1:
-            threads = min(16, os.cpu_count() or 1)
+        cpu = not args.no_cpu_baseline and world == 1
+        threads = host_threads()
+        if not args.no_config1 and world == 1:
+            out["config1"] = config1_of(args.steps, threads if cpu else None)
+        if cpu:
             out["cpu_baseline"] = cpu_baseline(threads)
             out["cpu_baseline_decode"] = cpu_decode_baseline(threads)
         emit(out)

@@ -194,3 +194,34 @@ def test_direct_accumulation_parameters_complete_once():
     for rank, flat, early in res:
         assert early >= 1                                   # at least one bucket went out from a hook
         assert abs(flat - ref).max() < 1e-6, (rank, abs(flat - ref).max())
+
+
+def test_arena_keeps_packed_qkv_gradients_adjacent():
+    """GradArena lays the q | k | v projections that MultiHeadedAttention.pack_qkv packed into one matrix out the same way
+    for their gradients (weights q, k, v consecutive in forward order, then the three biases), so that under data
+    parallelism ops.AttnSublayerFn still issues ONE weight-gradient launch per attention block; every slice stays
+    256-byte aligned, every parameter gets exactly one slice and the buckets still tile the arena."""
+    from transvae_amd import ops, synth
+    from transvae_amd.parallel import GradArena
+    from transvae_amd.trans_models import MultiHeadedAttention, build_encoder_decoder
+    model = build_encoder_decoder(26, 3, 128, 128, 128, 4, 0.1, False, False, 256, 2, 1, 126, 125)
+    mhas = [m for m in model.modules() if isinstance(m, MultiHeadedAttention)]
+    assert len(mhas) == 10
+    for m in mhas:
+        m.pack_qkv()
+    arena = GradArena(model, n_buckets=4)
+    params = [p for p in model.parameters() if p.requires_grad]
+    assert len(arena.params) == len(params) and {id(p) for p in arena.params} == {id(p) for p in params}
+    for m in mhas:
+        gw = [l.weight.grad for l in m.linears[:3]]
+        gb = [l.bias.grad for l in m.linears[:3]]
+        assert ops._adjacent(*gw) and ops._adjacent(*gb)
+        assert ops._adjacent(gw[1], gw[2]) and ops._adjacent(gb[1], gb[2])        # the k | v run of source attention
+        assert ops._run(gw).shape == (3 * 128, 128)
+    base = arena.flat.data_ptr()
+    spans = sorted((p.grad.data_ptr() - base, p.numel() * 4) for p in params)
+    for (o, n), (o2, _) in zip(spans, spans[1:]):
+        assert o % 256 == 0 and o + n <= o2                                    # aligned, disjoint
+    assert arena.buckets[0][0] == 0 and arena.buckets[-1][1] == arena.flat.numel()
+    assert all(a[1] == b[0] for a, b in zip(arena.buckets, arena.buckets[1:]))
+    assert sum(b[2] for b in arena.buckets) == len(params)

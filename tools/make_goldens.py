@@ -115,11 +115,13 @@ def run_chunk(tm, loss_mod, data_mod, vae, toks, props, eps, beta, dtype):
 
 
 def gate_margins(vae, toks, eps):
-    """Per-molecule distance of every bottleneck gate from its switching point, measured on the
-    reference in float64 with forward hooks: max-pool pairs |u - v|, ReLU inputs |x| of the conv
-    stack, of decoder.linear and of the three deconv layers.  ReLU / MaxPool make the gradient
-    discontinuous there: two correct fp32 implementations can legitimately pick different sides
-    when a margin is below their rounding error, so golden inputs are chosen with safe margins.
+    """Per-molecule distance of every gate from its switching point, measured on the REFERENCE in float64 with forward
+    hooks: max-pool pairs |u - v| and ReLU inputs of the conv stack, the ReLU inputs of decoder.linear and of the three
+    deconv layers, and the hidden ReLU inputs of the seven feed-forward blocks (w_1 outputs: 910,000 gates per
+    trans4x-256 molecule).  ReLU / MaxPool make the gradient discontinuous there: two correct fp32 implementations can
+    legitimately pick different sides when a margin is below their rounding error, so golden inputs are chosen with
+    safe margins.  Margins are RELATIVE to the layer's rms pre-activation over the batch (an fp32 product's error
+    scales with the size of its terms), the convention of oracle.gate_margins and tests/helpers.GATE_THRESHOLDS.
     Returns {name: (B,) tensor}."""
     model = vae.model
     model.double()
@@ -131,13 +133,14 @@ def gate_margins(vae, toks, eps):
         def f(mod, inp, out):
             L = out.shape[-1] // 2 * 2
             u, v = out[..., 0:L:2], out[..., 1:L:2]
-            m["pool%d" % i] = (u - v).abs().flatten(1).min(1)[0]
-            m["crelu%d" % i] = torch.maximum(u, v).abs().flatten(1).min(1)[0]
+            rms = out.pow(2).mean().sqrt()
+            m["pool%d" % i] = (u - v).abs().flatten(1).min(1)[0] / rms
+            m["crelu%d" % i] = torch.maximum(u, v).abs().flatten(1).min(1)[0] / rms
         return f
 
     def relu_hook(name):
         def f(mod, inp, out):
-            m[name] = out.abs().flatten(1).min(1)[0]
+            m[name] = out.abs().flatten(1).min(1)[0] / out.pow(2).mean().sqrt()
         return f
 
     for i, seq in enumerate(model.encoder.conv_bottleneck.conv_layers):
@@ -145,6 +148,9 @@ def gate_margins(vae, toks, eps):
     hooks.append(model.decoder.linear.register_forward_hook(relu_hook("dlin")))
     for i, seq in enumerate(model.decoder.deconv_bottleneck.deconv_layers):
         hooks.append(seq[0].register_forward_hook(relu_hook("deconv%d" % i)))
+    for mod_name, mod in model.named_modules():
+        if mod_name.endswith("feed_forward.w_1"):
+            hooks.append(mod.register_forward_hook(relu_hook("ffn:" + mod_name[:-len(".w_1")])))
     src = toks.long()
     tgt = toks[:, :-1].long()
     src_mask = (src != vae.pad_idx).unsqueeze(-2)
@@ -172,31 +178,46 @@ def gate_margins(vae, toks, eps):
 
 
 ENC_GATES = ("pool0", "crelu0", "pool1", "crelu1", "pool2", "crelu2")
-DEC_GATES = (("dlin", 1.0), ("deconv0", 1.0), ("deconv1", 1.0), ("deconv2", 4.0))   # (name, weight)
+DEC_GATES = ("dlin", "deconv0", "deconv1", "deconv2")
 
 
-def safe_step_inputs(vae, name, n_cand=40):
-    """Choose every molecule (tokens, then its eps row) among n_cand seeded candidates so that its
-    own gate margins are as large as possible; gates of one molecule do not depend on the others."""
+def _gate_score(m, names):
+    """(n,) smallest margin / threshold over the named gates (>= 1: every such gate of the molecule is outside its
+    unsafe band).  Thresholds: tests/helpers.GATE_THRESHOLDS for the bottleneck, FFN_GATE_THRESHOLD for 'ffn:' gates."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import FFN_GATE_THRESHOLD, GATE_THRESHOLDS
+    rows = [m[k] / (FFN_GATE_THRESHOLD if k.startswith("ffn:") else GATE_THRESHOLDS[k]) for k in names]
+    return torch.stack(rows).min(0)[0]
+
+
+def safe_step_inputs(vae, name, n_cand=48, lens=(1, 2, 126, 125, 35, 40, 22, 60, 90, 33, 47, 10), seed_shift=0):
+    """Choose every molecule (tokens, then its eps row) among n_cand seeded candidates so that its own gate margins are
+    as large as possible RELATIVE TO THEIR THRESHOLDS; gates of one molecule do not depend on the others.  Tokens decide
+    the encoder side (conv bottleneck gates + the three encoder feed-forward blocks), eps -- with the tokens fixed --
+    the decoder side (decoder.linear, deconv gates, the feed-forward blocks of final_encodes and the decoder layers).
+    Round 3: the feed-forward gates are screened too (round 2 screened the bottleneck only and had to keep a 4e-5
+    gradient floor: one marginal FFN ReLU deciding differently puts 2-3e-5 on the tensors upstream of it)."""
     from transvae_amd import synth
-    lens = [1, 2, 126, 125, 35, 40, 22, 60, 90, 33, 47, 10]
     B = len(lens)
-    base = zlib.crc32(name.encode()) & 0xFFFF
+    base = (zlib.crc32(name.encode()) + seed_shift) & 0xFFFF
     cand = torch.cat([synth.synth_tokens(n_cand, seed=base + 101 * i, lengths=[L] * n_cand) for i, L in enumerate(lens)])
     m = gate_margins(vae, cand, torch.zeros(B * n_cand, 128))
-    enc = torch.stack([m[k] for k in ENC_GATES]).min(0)[0].view(B, n_cand)
-    pick = enc.argmax(1)
+    enc_names = list(ENC_GATES) + [k for k in m if k.startswith("ffn:encoder.")]
+    pick = _gate_score(m, enc_names).view(B, n_cand).argmax(1)
     toks = torch.stack([cand[i * n_cand + int(pick[i])] for i in range(B)])
     rng = np.random.default_rng(base + 5)
     eps_c = torch.from_numpy(rng.standard_normal((B, n_cand, 128)).astype(np.float32))
     m2 = gate_margins(vae, toks.repeat_interleave(n_cand, 0), eps_c.view(B * n_cand, 128))
-    dec = torch.stack([m2[k] * w for k, w in DEC_GATES]).min(0)[0].view(B, n_cand)
-    pick2 = dec.argmax(1)
+    dec_names = list(DEC_GATES) + [k for k in m2 if k.startswith("ffn:decoder.")]
+    pick2 = _gate_score(m2, dec_names).view(B, n_cand).argmax(1)
     eps = torch.stack([eps_c[i, int(pick2[i])] for i in range(B)])
     props = torch.from_numpy(rng.uniform(0, 3, B).astype(np.float32))
     final = gate_margins(vae, toks, eps)
+    score = _gate_score(final, list(final))
     margins = {k: float(v.min()) for k, v in final.items()}
-    print("  inputs for %s: margins %s" % (name, {k: "%.1e" % v for k, v in margins.items()}))
+    print("  inputs for %s: smallest margin / threshold per molecule %s" % (name, ["%.1f" % float(v) for v in score]))
+    print("  margins %s" % {k: "%.1e" % v for k, v in margins.items()})
+    assert float(score.min()) >= 1.0, "a molecule of %s kept a gate inside its unsafe band: raise n_cand" % name
     return toks, props, eps, 0, margins
 
 
@@ -246,16 +267,19 @@ def golden_step(tm, loss_mod, data_mod, name, cfg):
           % (np.median(rec["grad_ref_f32_relerr"][nz]), rec["grad_ref_f32_relerr"][nz].max()))
 
 
+ACCUM_KEYS = ["generator.proj.bias", "encoder.norm.a_2", "encoder.z_means.bias",
+              "decoder.layers.0.self_attn.linears.3.bias", "src_embed.0.lut.weight",
+              "encoder.conv_bottleneck.conv_layers.1.0.bias", "decoder.linear.bias",
+              "decoder.layers.2.feed_forward.w_2.bias", "encoder.predict_len1.bias",
+              "decoder.deconv_bottleneck.deconv_layers.1.0.bias"]
+
+
 def golden_accum(tm, loss_mod, data_mod):
     """2 chunks accumulated, NoamOpt.step, 3 steps (trans1x-128)."""
     from transvae_amd import synth
     name, cfg = "1x128_zinc", CONFIGS["1x128_zinc"]
     vae = build(tm, cfg, WARMUP_STEPS=100)   # short warm-up so that updates are well above fp32 eps
-    keys = ["generator.proj.bias", "encoder.norm.a_2", "encoder.z_means.bias",
-            "decoder.layers.0.self_attn.linears.3.bias", "src_embed.0.lut.weight",
-            "encoder.conv_bottleneck.conv_layers.1.0.bias", "decoder.linear.bias",
-            "decoder.layers.2.feed_forward.w_2.bias", "encoder.predict_len1.bias",
-            "decoder.deconv_bottleneck.deconv_layers.1.0.bias"]
+    keys = ACCUM_KEYS
     rec = {"keys": np.array(keys)}
     rng = np.random.default_rng(11)
     all_toks, all_eps, rates, losses = [], [], [], []
@@ -292,6 +316,74 @@ def golden_accum(tm, loss_mod, data_mod):
                losses=np.array(losses), beta=np.float64(0.01), warmup=np.int64(100))
     np.savez_compressed(os.path.join(OUT, "accum_1x128_zinc.npz"), **rec)
     print("accum rates", rates)
+
+
+def golden_accum_4x256(tm, loss_mod, data_mod, chunks=5, csize=6, steps=3):
+    """The headline model's optimizer step as VAEShell.train runs it (trans_models.py:202-238, opt.py:21-36): `chunks`
+    chunks of `csize` molecules, gradients ACCUMULATED over the chunks (no 1/chunks), then NoamOpt.step; `steps` steps.
+    Run twice on the reference -- float32 (what it really does) and float64 (the truth) -- so that the test can hold the
+    build's parameter updates to the reference's OWN fp32-vs-fp64 error instead of a guessed bar.  Inputs are chosen
+    gate-safe for step 1 (the weights move by ~1e-7 relative per step, margins stay what they are to three digits)."""
+    name, cfg = "4x256_zinc", CONFIGS["4x256_zinc"]
+    warmup = 100
+    lens = (35, 28, 41, 33, 37, 126, 30, 44, 36, 22, 39, 31, 34, 2, 38, 29, 42, 35, 33, 40, 27, 36, 60, 32, 45, 34, 31, 38, 90, 30)
+    assert len(lens) == chunks * csize
+    inputs = []
+    probe = build(tm, cfg, WARMUP_STEPS=warmup)
+    for step in range(steps):
+        toks, _, eps, _, margins = safe_step_inputs(probe, "accum4x256_step%d" % step, n_cand=48, lens=lens, seed_shift=977 * step)
+        inputs.append((toks, eps))
+    rec = {"keys": np.array(ACCUM_KEYS), "chunks": np.int64(chunks), "csize": np.int64(csize), "warmup": np.int64(warmup),
+           "beta": np.float64(0.01), "tokens": np.stack([t.numpy().astype(np.int8) for t, _ in inputs]),
+           "eps": np.stack([e.numpy() for _, e in inputs])}
+    for tag, dtype in (("f32", torch.float32), ("f64", torch.float64)):
+        vae = build(tm, cfg, WARMUP_STEPS=warmup)
+        vae.model.to(dtype)
+        adam = torch.optim.Adam(vae.model.parameters(), lr=0, betas=(0.9, 0.98), eps=1e-9)     # as build_model (:703-705)
+        from transvae.opt import NoamOpt
+        vae.optimizer = NoamOpt(256, vae.params["LR_SCALE"], warmup, adam)
+        named = dict(vae.model.named_parameters())
+        for k in ACCUM_KEYS:
+            rec["p0/%s" % k] = named[k].detach().double().numpy().copy()
+        losses, rates = [], []
+        for step in range(steps):
+            toks_all, eps_all = inputs[step]
+            vae.model.zero_grad()
+            for c in range(chunks):
+                sl = slice(c * csize, (c + 1) * csize)
+                toks, eps = toks_all[sl], eps_all[sl]
+                model = vae.model
+                model.eval()
+                src, tgt = toks.long(), toks[:, :-1].long()
+                src_mask = (src != vae.pad_idx).unsqueeze(-2)
+                tgt_mask = data_mod.make_std_mask(tgt, vae.pad_idx)
+                orig = torch.randn_like
+                torch.randn_like = lambda t, *a, **k: eps.to(t.dtype)
+                try:
+                    x_out, mu, logvar, pred_len, pred_prop = model(src, tgt, src_mask, tgt_mask)
+                finally:
+                    torch.randn_like = orig
+                out = loss_mod.trans_vae_loss(src, x_out, mu, logvar, src_mask.sum(dim=-1), pred_len,
+                                              torch.zeros(csize, dtype=dtype), pred_prop,
+                                              vae.params["CHAR_WEIGHTS"].to(dtype), 0.01)
+                losses.append(float(out[0]))
+                out[0].backward()
+            vae.optimizer.step()
+            rates.append(vae.optimizer.state_dict["rate"])
+            for k in ACCUM_KEYS:
+                rec["p_%s_step%d/%s" % (tag, step + 1, k)] = named[k].detach().double().numpy().copy()
+        rec["losses_" + tag] = np.array(losses)
+        rec["rates"] = np.array(rates)
+    # the reference's own fp32 error on every recorded UPDATE (p_step - p0), relative L2 against its float64 run
+    errs = []
+    for step in range(1, steps + 1):
+        for k in ACCUM_KEYS:
+            d32 = rec["p_f32_step%d/%s" % (step, k)] - rec["p0/%s" % k]
+            d64 = rec["p_f64_step%d/%s" % (step, k)] - rec["p0/%s" % k]
+            errs.append(np.linalg.norm(d32 - d64) / np.linalg.norm(d64))
+    rec["update_ref_f32_relerr"] = np.array(errs).reshape(steps, len(ACCUM_KEYS))
+    np.savez_compressed(os.path.join(OUT, "accum_4x256_zinc.npz"), **rec)
+    print("accum 4x256: rates", rates, "reference fp32-vs-fp64 update rel-L2: median %.2e max %.2e" % (np.median(errs), np.max(errs)))
 
 
 def golden_decode(tm, name, cfg, n=32):
@@ -593,6 +685,10 @@ def main():
         return golden_data(data_mod, util)
     if len(sys.argv) > 1 and sys.argv[1] == "accum":
         return golden_accum(tm, loss_mod, data_mod)
+    if len(sys.argv) > 1 and sys.argv[1] == "accum4x256":
+        return golden_accum_4x256(tm, loss_mod, data_mod)
+    if len(sys.argv) > 1 and sys.argv[1] == "decode4x256":
+        return golden_decode(tm, "4x256_zinc", CONFIGS["4x256_zinc"], n=256)
     if len(sys.argv) > 1 and sys.argv[1] == "ckpt":
         return golden_ckpt(tm, loss_mod, data_mod)
     if len(sys.argv) > 1 and sys.argv[1] == "sampling":
@@ -607,8 +703,9 @@ def main():
     for name, cfg in CONFIGS.items():
         golden_step(tm, loss_mod, data_mod, name, cfg)
     golden_accum(tm, loss_mod, data_mod)
+    golden_accum_4x256(tm, loss_mod, data_mod)
     golden_decode(tm, "1x128_zinc", CONFIGS["1x128_zinc"])
-    golden_decode(tm, "4x256_zinc", CONFIGS["4x256_zinc"])
+    golden_decode(tm, "4x256_zinc", CONFIGS["4x256_zinc"], n=256)
     golden_attn(tm, data_mod)
     golden_attn(tm, data_mod, "4x256_pubchem_pp")
     golden_ckpt(tm, loss_mod, data_mod)

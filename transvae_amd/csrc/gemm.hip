@@ -474,6 +474,10 @@ int wide_mode() {
   static int m = [] { const char* e = getenv("TVAE_GEMM_WIDE"); return e ? atoi(e) : 1; }();
   return m;
 }
+bool auto_split_enabled() {   // TVAE_GEMM_AUTOSPLIT=0 switches the tail-balance split of pure products off (read once)
+  static bool on = [] { const char* e = getenv("TVAE_GEMM_AUTOSPLIT"); return !e || atoi(e) != 0; }();
+  return on;
+}
 bool fp32_dma_enabled() {   // TVAE_GEMM_DMA=1: exact-fp32 NT products take the LDS-DMA kernel too (experiment switch; read once)
   static bool on = [] { const char* e = getenv("TVAE_GEMM_DMA"); return e && atoi(e) == 1; }();
   return on;
@@ -505,6 +509,39 @@ static int gemm_impl(const float* A, int lda, const float* B, int ldb, float* C,
   bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && aligned16(A) && aligned16(B) &&
                  (a_km ? (M % 4 == 0) : (K % 4 == 0)) && (b_km ? (N % 4 == 0) : (K % 4 == 0));
   if (batch > 1 && (sA % 4 || sB % 4)) aligned = false;
+  // Tail balance for pure products (nothing fused, C contiguous): a launch of few tiles with a long K -- the data gradients of
+  // the conv bottleneck: 51-536 tiles of K = 512..2816 -- leaves CUs idle or gives some CUs 3 tiles and others 2, and the
+  // launch takes as long as the busiest CU.  Such a product is cut into 2-8 K slabs that ADD into a zeroed C (the split-K
+  // path of the weight gradients; the memset is asynchronous on the same stream), so the work items are several per CU.
+  const bool bf16_ = dtype == TVAE_BF16;
+  if (!(flags & ~(TVAE_GEMM_A_KMAJOR | TVAE_GEMM_B_KMAJOR)) && !bias && !residual && !a_rowsum && batch == 1 && !bf16_ &&
+      ldc == N && K >= 512 && auto_split_enabled()) {
+    const bool wide = wide_mode() >= 1 && N > 128 && N <= 160 && (flags & TVAE_GEMM_A_KMAJOR ? 1 : 0) == (flags & TVAE_GEMM_B_KMAJOR ? 1 : 0);
+    const int t = wide ? cdiv(M, 128) * cdiv(N, 160) : cdiv(M, BM) * cdiv(N, BN);
+    // Measured (profiles/r3_gemm_shapes_step_fp32.txt): worth it only where less than half of the CUs would have a tile at all
+    // (51 tiles: 103 -> 53 us) -- then the slab count with the best balance -- and on the wide tile when the busiest CU
+    // has 3 tiles against an average of 2.1 (536 tiles: 744 -> 701 us); 172 tiles cut in 4 ran SLOWER (136 -> 175 us: the
+    // atomic epilogue of a 14-step slab costs more than the idle CUs).  Every slab keeps at least 256 of K.
+    auto eff = [&](int sp) { const double x = (double)t * sp / 256.0; return x / (double)cdiv((long)t * sp, 256); };
+    int best = 1;
+    if (t < 128) {
+      for (int sp = 2; sp <= 8 && K / sp >= 256 && (long)t * sp <= 512; ++sp)
+        if (eff(sp) > eff(best) + 0.02) best = sp;
+    } else if (wide && eff(1) < 0.75) {
+      for (int sp = 2; sp <= 4 && K / sp >= 256; ++sp)
+        if (eff(sp) >= 0.88) { best = sp; break; }
+    }
+    if (best > 1) {
+      if (hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+        tvae_set_error("tvae_gemm: hipMemsetAsync of the split product's output failed");
+        return TVAE_E_LAUNCH;
+      }
+      return gemm_impl(A, lda, B, ldb, C, ldc, M, N, K, nullptr, nullptr, 0, alpha, flags | TVAE_GEMM_SPLITK | (best << 24), rng, site,
+                       p_drop, nullptr, dtype, stream, 1, 0, 0, 0, 0);
+    }
+  }
+  const int forced_splits = (flags >> 24) & 15;      // internal: set by the tail-balance path above
+  flags &= ~(15 << 24);
   GemmArgs g;
   g.sA = sA; g.sB = sB; g.sC = sC; g.sR = sR;
   g.split = 0;
@@ -566,7 +603,7 @@ static int gemm_impl(const float* A, int lda, const float* B, int ldb, float* C,
       g.k_per_split = K;
       if (flags & TVAE_GEMM_SPLITK) {
         const int wtiles = cdiv(M, 128) * cdiv(N, 160), ktiles = cdiv(K, 32);
-        splits = 768 / wtiles;                       // one round of resident workgroups: 256 CUs x 3
+        splits = forced_splits ? forced_splits : 768 / wtiles;     // one round of resident workgroups: 256 CUs x 3
         if (splits > ktiles / 8) splits = ktiles / 8;
         if (splits < 1) splits = 1;
         g.k_per_split = cdiv(ktiles, splits) * 32;
@@ -583,7 +620,7 @@ static int gemm_impl(const float* A, int lda, const float* B, int ldb, float* C,
     // one full round of resident workgroups, each with at least 256 of K: more splits only add
     // atomic epilogues, fewer leave CUs idle
     int ktiles = cdiv(K, 32);
-    splits = (BK == 16 ? SLOTS16 : SLOTS32) / tiles;
+    splits = forced_splits ? forced_splits : (BK == 16 ? SLOTS16 : SLOTS32) / tiles;
     if (splits > ktiles / 8) splits = ktiles / 8;
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;

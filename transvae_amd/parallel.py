@@ -69,8 +69,29 @@ class GradArena:
 
     def __init__(self, model, n_buckets=4):
         params = [p for p in model.parameters() if p.requires_grad]
-        # backward reaches parameters roughly in reverse registration order
-        order = list(reversed(params))
+        # backward reaches parameters roughly in reverse registration order -- except that the q | k | v projections of an
+        # attention block that MultiHeadedAttention.pack_qkv laid out as row blocks of one matrix keep that layout for
+        # their GRADIENTS too (weights q, k, v consecutive, then biases q, k, v, in forward order): ops.AttnSublayerFn
+        # then still finds them adjacent and issues ONE split-K launch for the three weight and bias gradients, as in the
+        # single-GPU step (256 x 256 blocks and 256-float biases are whole numbers of 64-float slices: no padding between)
+        from . import ops
+        runs = {}
+        for m in model.modules():
+            lin = getattr(m, "linears", None)
+            if lin is None or len(lin) < 3:
+                continue
+            Ws, bs = [l.weight for l in lin[:3]], [l.bias for l in lin[:3]]
+            if all(w.requires_grad for w in Ws + bs) and ops._adjacent(*[w.data for w in Ws]) and ops._adjacent(*[b.data for b in bs]):
+                for run in (Ws, bs):
+                    for q in run:
+                        runs[id(q)] = run
+        order, seen = [], set()
+        for p in reversed(params):
+            if id(p) in seen:
+                continue
+            for q in runs.get(id(p), [p]):
+                order.append(q)
+                seen.add(id(q))
         # every slice starts on a 256-byte boundary: the weight-gradient kernels add 128-byte runs with fp32 atomics,
         # and a slice that starts mid cache line makes every run straddle two (measured: +16 us on each such launch)
         pad = lambda n: (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN

@@ -184,8 +184,9 @@ int tvae_attn_fwd(const float* q, int ldq, const float* k, int ldk, const float*
                   const uint32_t* rng, uint32_t site, float p_drop, int dtype, void* stream);
 /* Backward of the above.  dq/dk/dv use the same addressing as q/k/v (may be strided views);
  * every element of the addressed head slices is written.  dsum is workspace, 16-byte aligned, of
- * R4 + 4*R floats with R = B*h*Lq and R4 = R rounded up to a multiple of 4: the per-row sum_j P_j dP_j
- * followed by four 32-bit dropout keep words per row (written by the dQ kernel, read by the dK/dV kernel). */
+ * R4 + 4*R + B*h floats with R = B*h*Lq and R4 = R rounded up to a multiple of 4: the per-row sum_j P_j dP_j,
+ * four 32-bit dropout keep words per row and one word per (molecule, head) naming its live key tiles (written by the
+ * dQ kernel, read by the dK/dV kernel, which deals its waves to the key tiles that hold a visible key). */
 int tvae_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                   const float* o, int ldo, const float* d_o, int lddo, const float* lse,
                   float* dq, int lddq, float* dk_, int lddk, float* dv, int lddv, float* dsum,

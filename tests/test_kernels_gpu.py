@@ -259,8 +259,8 @@ def test_attention_dead_tiles_exact(causal, mode):
     """Key tiles whose mask words are all zero are skipped (their weights are exact zeros).  Lengths on
     every 32-key tile boundary, with and without the causal mask, dropout on: (a) against the oracle
     math; (b) the values of masked keys must not matter at all -- bit-identical outputs and gradients
-    when their K / V rows are replaced by large finite junk; (c) dK / dV bit-identical to the
-    full-mask instantiation, whose dK/dV kernel skips nothing.  Molecule 0 is fully masked (uniform
+    when their K / V rows are replaced by large finite junk; (c) dK / dV equal to the
+    full-mask instantiation's, whose dK/dV kernel skips nothing (bit-identical where the waves are not re-dealt).  Molecule 0 is fully masked (uniform
     attention over masked keys: nothing may be skipped there)."""
     from transvae_amd import ops
     prev = ops.compute_dtype()
@@ -295,7 +295,12 @@ def _dead_tiles_body(causal, tol_o, tol_g):
 
     of, lsef, _ = ops.attn_fwd(flat(q), flat(k), flat(v), B, h, L, L, dk, spec_full)
     dqf, dkf, dvf = ops.attn_bwd(flat(q), flat(k), flat(v), of, flat(do), lsef, B, h, L, L, dk, spec_full)
-    assert torch.equal(o, of) and torch.equal(dq, dqf) and torch.equal(dkk, dkf) and torch.equal(dv, dvf)
+    assert torch.equal(o, of) and torch.equal(dq, dqf)
+    # dK / dV: with 1 or 2 live key tiles the waves of the key-masked instantiation share a key tile and add their partial
+    # sums over the query tiles in another grouping than the full-mask instantiation's single chain: same terms, rounding apart
+    assert rel_l2(dkk.cpu(), dkf.cpu()) < (1e-6 if tol_g < 1e-3 else 1e-2) and rel_l2(dv.cpu(), dvf.cpu()) < (1e-6 if tol_g < 1e-3 else 1e-2)
+    full_rows = (lens[:, None] > 64).expand(B, L).reshape(-1).to(dev())        # molecules with 3-4 live tiles: one chain, same bits
+    assert torch.equal(dkk[full_rows], dkf[full_rows]) and torch.equal(dv[full_rows], dvf[full_rows])
 
     # junk in the masked keys (molecule 0 excluded: its masked keys DO carry weight), dropout on
     ops.seed_rng(dev(), 5)

@@ -359,6 +359,21 @@ void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) mwt[t] = tile_mask<GENERIC>(a, b, qs, t, key_bits);
     live = live_tiles(mwt);
+    {
+      // For the dK/dV kernel, which keeps the KEY on the lane: which key tiles of this molecule have a visible key at all,
+      // and whether any query row is fully masked (then masked keys carry weight and nothing is dead).  One word per
+      // workgroup behind the keep words of the workspace; that kernel reads it first and deals its waves to live tiles.
+      const bool wave_full_row = __ballot(qvalid && (mwt[0] | mwt[1] | mwt[2] | mwt[3]) == 0U) != 0ULL;
+      const bool any_full_row = __syncthreads_or(wave_full_row);
+      if (tid == 0) {
+        uint32_t n = 0, list = 0;
+        for (int t = 0; t < 4; ++t)
+          if (key_bits[t] != 0U) { list |= (uint32_t)t << (2 * n); ++n; }
+        const size_t rows_pad_ = ((size_t)a.B * a.h * a.Lq + 3) & ~(size_t)3;
+        reinterpret_cast<uint32_t*>(a.dsum)[rows_pad_ + 4 * (size_t)a.B * a.h * a.Lq + blockIdx.x] =
+            n | ((any_full_row || (GENERIC && a.full_mask)) ? 0U : 8U) | (list << 4);
+      }
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       if (!live.t[t]) continue;
@@ -433,16 +448,35 @@ void attn_bwd_dq_kernel(AttnArgs a) {
 // Key on the lane: S = Q K^T and dP = dO V^T come out as [query regs][key lanes], which is the
 // B operand of dV^T = dO^T P and dK^T = Q^T dS directly.  Row statistics, dsum and the dropout keep
 // words come from the dQ kernel's workspace (one LDS broadcast read per query).
+//
+// Waves are DEALT to the live key tiles.  A SMILES row has ~36 of 127 positions, so two of the four key tiles hold no
+// visible key at all, and with one wave per key tile two waves of every workgroup had nothing to do while the other two
+// walked all four query tiles (the kernel's time was that serial chain).  The dQ kernel leaves one word per workgroup:
+// the live key tiles and whether any row is fully masked.  With 2 live key tiles each gets two waves (query tiles 0-1
+// and 2-3), with 1 all four waves take one query tile each; the partial dK / dV of the waves that share a key tile are
+// added through LDS in a fixed order (Q / dO tiles are dead by then).  3-4 live tiles, a fully masked row or a (B,Lq,Lk)
+// mask: one wave per key tile as before.
 template <int DK, bool GENERIC, bool BF>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
   constexpr int LS = DK + 4, HALF = DK / 2, NU = DK / 32;
-  __shared__ __attribute__((aligned(16))) float Qs[128 * LS];
-  __shared__ __attribute__((aligned(16))) float Gs[128 * LS];   // dO
+  __shared__ __attribute__((aligned(16))) float QG[2 * 128 * LS];  // Q tile, then dO tile; afterwards the dK / dV exchange
+  float* const Qs = QG;
+  float* const Gs = QG + 128 * LS;
   __shared__ __attribute__((aligned(16))) float4 stat_s[128];     // {row max, 1/row sum, dsum, -} per query
   __shared__ __attribute__((aligned(16))) uint32_t keep_s[128][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const int b = blockIdx.x / a.h, head = blockIdx.x % a.h;
-  const int key = 32 * wave + r;
+  const size_t rows_pad = ((size_t)a.B * a.h * a.Lq + 3) & ~(size_t)3;
+
+  // the workgroup's word from the dQ kernel (uniform: a scalar load), then every vector load of the prologue in one burst
+  const uint32_t info = reinterpret_cast<const uint32_t*>(a.dsum)[rows_pad + 4 * (size_t)a.B * a.h * a.Lq + blockIdx.x];
+  const int n_live = info & 7;
+  const bool skip_ok = (info & 8U) != 0U;
+  const int share = (skip_ok && n_live == 2) ? 2 : ((skip_ok && n_live == 1) ? 4 : 1);   // waves per key tile
+  int kt = wave, tq0 = 0, tq1 = 4;
+  if (share == 2) { kt = (info >> (4 + 2 * (wave >> 1))) & 3; tq0 = 2 * (wave & 1); tq1 = tq0 + 2; }
+  if (share == 4) { kt = (info >> 4) & 3; tq0 = wave; tq1 = wave + 1; }
+  const int key = 32 * kt + r;
   const bool kvalid = key < a.Lk;
   const int ks = kvalid ? key : 0;
 
@@ -460,7 +494,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
   const int srow = min(tid & 127, a.Lq - 1);
   const size_t prow = (size_t)(b * a.h + head) * a.Lq + srow;
   const float st_mx = a.lse_in[2 * prow], st_inv = a.lse_in[2 * prow + 1], st_ds = a.dsum[prow];
-  const size_t rows_pad = ((size_t)a.B * a.h * a.Lq + 3) & ~(size_t)3;
   const uint32_t* kwp = dc.on ? reinterpret_cast<const uint32_t*>(a.dsum) + rows_pad + 4 * prow
                               : reinterpret_cast<const uint32_t*>(a.dsum);          // any readable 16 bytes
   const uint4 kw = *reinterpret_cast<const uint4*>(kwp);
@@ -474,15 +507,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     *reinterpret_cast<uint4*>(&keep_s[tid][0]) = (ok && dc.on) ? kw : make_uint4(~0U, ~0U, ~0U, ~0U);
   }
   const bool kbit = kvalid && (a.key_mask ? kmb != 0 : true);
-  // a fully masked query row (row max == the fill value) spreads weight over masked keys: then no tile is dead
-  const bool row_full = tid < a.Lq && st_mx == MASK_FILL;
-  const bool skip_ok = !__syncthreads_or(row_full) && !(GENERIC && a.full_mask);
+  __syncthreads();
 
   floatx16 dkacc[NU], dvacc[NU];
 #pragma unroll
   for (int u = 0; u < NU; ++u) { dkacc[u] = zero16(); dvacc[u] = zero16(); }
 #pragma unroll 1
-  for (int t = 0; t < 4; ++t) {
+  for (int t = tq0; t < tq1; ++t) {
     // (query tile t, this wave's key tile) is dead when no key of the wave is visible to any query of the tile
     const int q_last = min(32 * t + 31, a.Lq - 1);
     const bool lane_live = kbit && q_last >= 32 * t && (!a.causal || key <= q_last);
@@ -500,7 +531,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
         const float4 st = stat_s[qi];
         float sc = m ? s[i] * a.scale : MASK_FILL;
         float p = expf(sc - st.x) * st.y;
-        float ksc = ((keep_s[qi][wave] >> r) & 1U) ? dc.scale : 0.f;
+        float ksc = ((keep_s[qi][kt] >> r) & 1U) ? dc.scale : 0.f;
         pt = p * ksc;
         if (m) ds = p * (dp[i] * ksc - st.z) * a.scale;
       }
@@ -509,6 +540,51 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     }
     mma_cols_x_acc<DK, BF>(dvacc, Gs, 32 * t, hh, r, s);
     mma_cols_x_acc<DK, BF>(dkacc, Qs, 32 * t, hh, r, dp);
+  }
+  if (share > 1) {                       // workgroup-uniform
+    // waves that share a key tile: the first of them (the owner) adds the others' partial sums, in wave order
+    const int sub = wave % share;        // 0 = owner
+    __syncthreads();                     // every wave is done with the Q / dO tiles
+    if (sub != 0) {
+      float* slot = QG + (size_t)((wave / share) * (share - 1) + (sub - 1)) * (2 * NU * 16 * 64);
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          slot[(u * 16 + i) * 64 + lane] = dkacc[u][i];
+          slot[((NU + u) * 16 + i) * 64 + lane] = dvacc[u][i];
+        }
+    }
+    __syncthreads();
+    if (sub != 0) {
+      // every row of dK / dV is written: the waves without a tile of their own store the zeros of the DEAD key tiles
+      // (no visible key: exact zero gradient), the j-th such wave those of the j-th dead tile
+      int j = (wave / share) * (share - 1) + (sub - 1), dt = -1;
+      for (int t = 0; t < 4; ++t) {
+        bool is_live = false;
+        for (int l = 0; l < n_live; ++l) is_live = is_live || (int)((info >> (4 + 2 * l)) & 3) == t;
+        if (!is_live && j-- == 0) dt = t;
+      }
+      const int zkey = 32 * dt + r;
+      if (dt >= 0 && zkey < a.Lk) {
+        floatx16 z[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) z[u] = zero16();
+        store_rowmajor<DK>(a.dk + ((size_t)b * a.Lk + zkey) * a.lddk + head * DK, z, hh);
+        store_rowmajor<DK>(a.dv + ((size_t)b * a.Lk + zkey) * a.lddv + head * DK, z, hh);
+      }
+      return;
+    }
+    for (int o = 0; o < share - 1; ++o) {
+      const float* slot = QG + (size_t)((wave / share) * (share - 1) + o) * (2 * NU * 16 * 64);
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          dkacc[u][i] += slot[(u * 16 + i) * 64 + lane];
+          dvacc[u][i] += slot[((NU + u) * 16 + i) * 64 + lane];
+        }
+    }
   }
   if (kvalid) {
     store_rowmajor<DK>(a.dk + ((size_t)b * a.Lk + key) * a.lddk + head * DK, dkacc, hh);

@@ -447,8 +447,8 @@ def attn_bwd(q, k, v, o, do, lse, B, h, Lq, Lk, dk, spec, drop=None, out=None):
         dq = torch.empty((B * Lq, h * dk), device=q.device, dtype=torch.float32)
         dkk = torch.empty((B * Lk, h * dk), device=q.device, dtype=torch.float32)
         dv = torch.empty((B * Lk, h * dk), device=q.device, dtype=torch.float32)
-    rows = B * h * Lq                                   # workspace: dsum per row + 4 dropout keep words per row
-    dsum = torch.empty(((rows + 3) // 4 * 4 + 4 * rows,), device=q.device, dtype=torch.float32)
+    rows = B * h * Lq                                   # workspace: dsum per row + 4 dropout keep words per row + 1 word per (b, head)
+    dsum = torch.empty(((rows + 3) // 4 * 4 + 4 * rows + B * h,), device=q.device, dtype=torch.float32)
     r, s, p = _drop_args(drop)
     call("tvae_attn_bwd", _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
          _p(do), do.stride(0), _p(lse), _p(dq), dq.stride(0), _p(dkk), dkk.stride(0), _p(dv), dv.stride(0),

@@ -159,6 +159,12 @@ int tvae_layernorm_fwd(const float* x, const float* a, const float* b, float* y,
 int tvae_layernorm_bwd(const float* x, const float* a, const float* dy, const float* add_to,
                        float* dx, float* da, float* db, int rows, int d, float eps,
                        void* stream);
+/* The same, also writing dx_masked = dx * keep-scale of the dropout site (rng, site, p_drop) indexed (row, column) with
+ * pitch d: dx is the gradient arriving at the OUTPUT of the SublayerConnection in front (x + dropout(sublayer(norm(x))),
+ * transvae/trans_models.py:1101), whose two gradient products need it masked by that sublayer's residual dropout. */
+int tvae_layernorm_bwd_masked(const float* x, const float* a, const float* dy, const float* add_to, float* dx,
+                              float* dx_masked, float* da, float* db, int rows, int d, float eps,
+                              const uint32_t* rng, uint32_t site, float p_drop, void* stream);
 
 /*
  * Fused multi-head attention, one workgroup per (molecule, head), score tile kept on chip.

@@ -201,6 +201,38 @@ def test_train_chunk_bf16_mode_within_1e_2(cfg_name, gemm_mode):
     assert ferr[worst_f] < 0.25
 
 
+def test_premasked_residual_gradients_equal_masks_regenerated_in_the_gemms(monkeypatch):
+    """Training mode, dropout on.  The gradient at a sublayer's output is written by the next LayerNorm backward, which
+    also writes it with the sublayer's residual-dropout mask applied (tvae_layernorm_bwd_masked); the sublayer's two
+    gradient products then read that copy instead of regenerating the mask while staging.  Same seed, both ways: the
+    same losses bit for bit and the same gradients (weight gradients are summed with atomics: 2e-6)."""
+    from transvae_amd import ops, synth
+    g = load("step_4x256_zinc")
+    toks = torch.from_numpy(g["tokens"].astype(np.int64))
+    props, eps = torch.from_numpy(g["props"]), torch.from_numpy(g["eps"])
+    grads, losses = {}, {}
+    vae = build("4x256_zinc")                   # ONE model: dropout site ids are handed out at construction
+    vae.model.train()
+    for flag in ("0", "1"):
+        monkeypatch.setenv("TVAE_PREMASK", flag)
+        vae.model.zero_grad(set_to_none=True)
+        ops.seed_rng(torch.device("cuda:0"), 31)
+        ops.begin_step()
+        before = dict(ops.premask_stats)
+        out, _ = run_chunk(vae, toks, props, eps, 0.02)
+        out[0].backward()
+        used = ops.premask_stats["used"] - before["used"]
+        assert used == (0 if flag == "0" else 17), used        # every one of the 17 sublayers of the model took the masked copy
+        losses[flag] = [float(o.detach()) for o in out]
+        grads[flag] = {k: p.grad.detach().clone() for k, p in vae.model.named_parameters()}
+    assert losses["0"] == losses["1"]
+    for k in grads["0"]:
+        if float(grads["0"][k].norm()) < 1e-7:       # key-projection biases: the true gradient is exactly zero, both are rounding noise
+            assert float(grads["1"][k].norm()) < 1e-7, k
+            continue
+        assert rel_l2(grads["1"][k].cpu(), grads["0"][k].cpu()) < 2e-6, k
+
+
 def test_accumulation_noam_adam_matches_reference():
     g = load("accum_1x128_zinc")
     vae = build("1x128_zinc", WARMUP_STEPS=int(g["warmup"]), BATCH_CHUNKS=2, BATCH_SIZE=12)
@@ -230,9 +262,13 @@ def test_accumulation_noam_adam_4x256_matches_reference(gemm_mode):
     """The HEADLINE model's optimizer step against the reference's own run of it (tools/make_goldens.py
     golden_accum_4x256: 5 chunks of 6 gate-safe molecules accumulated -> NoamOpt.step, 3 steps, in float32 and float64):
     chunk losses at 1e-5, Noam rates exact, and the parameter UPDATES (p_step - p_0) of ten tensors per step against the
-    float64 run.  Bar per (step, tensor): max(1e-4, 4 x the reference's OWN fp32-vs-fp64 error there) -- Adam's first
-    updates are lr * g / |g| element by element, so an element whose gradient is within rounding of zero moves by a full
-    +-lr whichever way it rounds; the reference's own fp32 run is off by 1e-5 .. 5e-4 on these updates (stored)."""
+    float64 run.  Bar per (step, tensor): 1.5 x the reference's OWN fp32-vs-fp64 error there + 5e-6.  That error (6e-6 ..
+    5e-4, stored in the golden) is mostly the fp32 STORAGE of the parameter: an update of lr = 6e-5 .. 2e-4 added to a
+    value of order 1 keeps 3-4 digits, in any implementation -- measured, this build's numbers equal the reference's own
+    to 2-3 digits on all thirty (step, tensor) pairs (profiles/r3_parity_accum_4x256_*.txt).  The inputs of every step
+    are chosen gate-safe ON THAT STEP'S WEIGHTS: with inputs screened on the initial weights only, one feed-forward gate
+    deciding differently at step 3 showed up as 1e-3 on three tensors (Adam turns a 2e-5 gradient difference into a
+    relative update difference of that size where successive gradients nearly cancel)."""
     from helpers import record
     g = load("accum_4x256_zinc")
     chunks, csize = int(g["chunks"]), int(g["csize"])
@@ -258,7 +294,7 @@ def test_accumulation_noam_adam_4x256_matches_reference(gemm_mode):
             p0 = g["p0/" + k]
             err = rel_l2(named[k].detach().cpu().double().numpy() - p0, g["p_f64_step%d/%s" % (step, k)] - p0)
             ref = float(g["update_ref_f32_relerr"][step - 1, i])
-            bar = max(1e-4, 4.0 * ref)
+            bar = 1.5 * ref + 5e-6
             lines.append("%-4d %-55s %10.2e %10.2e %10.2e" % (step, k, err, ref, bar))
             if err >= bar:
                 bad.append((step, k, err, bar))

@@ -34,6 +34,7 @@ SIGNATURES = {
     "tvae_colsum": [_vp, _i, _vp, _i, _i, _i, _vp, _u, _f, _vp],
     "tvae_layernorm_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "tvae_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
+    "tvae_layernorm_bwd_masked": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _u, _f, _vp],
     "tvae_attn_fwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _u, _f, _i, _vp],
     "tvae_attn_bwd": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i,
                       _i, _i, _i, _i, _i, _f, _vp, _u, _f, _i, _vp],

@@ -75,9 +75,16 @@ template <int NPL>
 __global__ __launch_bounds__(512) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ a,
                                                      const float* __restrict__ dy, const float* __restrict__ add_to,
                                                      float* __restrict__ dx, float* __restrict__ da,
-                                                     float* __restrict__ db, int rows, int rows_per_wg, float eps) {
+                                                     float* __restrict__ db, int rows, int rows_per_wg, float eps,
+                                                     float* __restrict__ dxm, const uint32_t* __restrict__ rng,
+                                                     uint32_t site, float p_drop) {
   constexpr int d = 64 * NPL;
   __shared__ float red[2][8][d];
+  // dxm (optional): dx times the keep-scale of a dropout site indexed (row, column) with pitch d -- the residual dropout of
+  // the sublayer whose OUTPUT this LayerNorm read.  dx is that sublayer's incoming gradient, and its two gradient GEMMs
+  // need it masked: written here it costs one more store stream; regenerating the mask while staging costs both GEMMs
+  // a hash per float4 inside their k-loops (26 us on the d x d weight gradient, 28 us on the FFN's).
+  const DropCfg dcm = drop_cfg(dxm ? rng : nullptr, site, p_drop);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   float av[NPL], pa[NPL], pb[NPL];
   load_run<NPL>(av, a + lane * NPL);
@@ -128,6 +135,21 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const float* __restrict__ x
         g[r][i] = o;
       }
       store_run<NPL>(dx + off[r], g[r]);
+      if (dxm) {
+        const uint32_t e0 = (uint32_t)(off[r]);            // element index = row * d + column (host: rows * d < 2^32)
+        if constexpr (NPL % 4 == 0) {
+#pragma unroll
+          for (int i = 0; i < NPL; i += 4) {
+            float ks[4];
+            drop_scale4(dcm, e0 + i, ks);
+            g[r][i] *= ks[0]; g[r][i + 1] *= ks[1]; g[r][i + 2] *= ks[2]; g[r][i + 3] *= ks[3];
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < NPL; ++i) g[r][i] *= drop_scale(dcm, e0 + i);
+        }
+        store_run<NPL>(dxm + off[r], g[r]);
+      }
     }
   }
 #pragma unroll
@@ -471,11 +493,13 @@ extern "C" int tvae_layernorm_fwd(const float* x, const float* a, const float* b
   return TVAE_OK;
 }
 
-extern "C" int tvae_layernorm_bwd(const float* x, const float* a, const float* dy, const float* add_to, float* dx,
-                                  float* da, float* db, int rows, int d, float eps, void* stream) {
+static int layernorm_bwd_impl(const float* x, const float* a, const float* dy, const float* add_to, float* dx,
+                              float* da, float* db, int rows, int d, float eps, float* dxm, const uint32_t* rng,
+                              uint32_t site, float p_drop, void* stream) {
   TVAE_CHECK(x && a && dy && dx && da && db, TVAE_E_NULL, "tvae_layernorm_bwd: null pointer");
   TVAE_CHECK(rows > 0 && d % 64 == 0 && d >= 64 && d <= 512, TVAE_E_SHAPE,
              "tvae_layernorm_bwd: d=%d must be a multiple of 64 in [64,512], rows=%d", d, rows);
+  TVAE_CHECK(!dxm || (long)rows * d < (1L << 32), TVAE_E_SHAPE, "tvae_layernorm_bwd_masked: dropout index space exceeds 32 bits");
   hipStream_t s = (hipStream_t)stream;
   // The column sums da, db leave every workgroup as 2*d same-address atomics, and those, not the four
   // streams, were the kernel's limit (68 us with ~2000 workgroups of 4 waves, 47 us with the atomics
@@ -485,17 +509,29 @@ extern "C" int tvae_layernorm_bwd(const float* x, const float* a, const float* d
   const int threads = 512;
   dim3 grid(cdiv(rows, rpw)), block(threads);
   switch (d / 64) {
-    LN_DISPATCH_B(1, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
-    LN_DISPATCH_B(2, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
-    LN_DISPATCH_B(3, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
-    LN_DISPATCH_B(4, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
-    LN_DISPATCH_B(5, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
-    LN_DISPATCH_B(6, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
-    LN_DISPATCH_B(7, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
-    LN_DISPATCH_B(8, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps)
+    LN_DISPATCH_B(1, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps, dxm, rng, site, p_drop)
+    LN_DISPATCH_B(2, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps, dxm, rng, site, p_drop)
+    LN_DISPATCH_B(3, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps, dxm, rng, site, p_drop)
+    LN_DISPATCH_B(4, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps, dxm, rng, site, p_drop)
+    LN_DISPATCH_B(5, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps, dxm, rng, site, p_drop)
+    LN_DISPATCH_B(6, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps, dxm, rng, site, p_drop)
+    LN_DISPATCH_B(7, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps, dxm, rng, site, p_drop)
+    LN_DISPATCH_B(8, ln_bwd_kernel, x, a, dy, add_to, dx, da, db, rows, rpw, eps, dxm, rng, site, p_drop)
   }
   TVAE_LAUNCH_CHECK("tvae_layernorm_bwd");
   return TVAE_OK;
+}
+
+extern "C" int tvae_layernorm_bwd(const float* x, const float* a, const float* dy, const float* add_to, float* dx,
+                                  float* da, float* db, int rows, int d, float eps, void* stream) {
+  return layernorm_bwd_impl(x, a, dy, add_to, dx, da, db, rows, d, eps, nullptr, nullptr, 0, 0.f, stream);
+}
+
+extern "C" int tvae_layernorm_bwd_masked(const float* x, const float* a, const float* dy, const float* add_to, float* dx,
+                                         float* dx_masked, float* da, float* db, int rows, int d, float eps,
+                                         const uint32_t* rng, uint32_t site, float p_drop, void* stream) {
+  TVAE_CHECK(dx_masked && rng && p_drop > 0.f, TVAE_E_NULL, "tvae_layernorm_bwd_masked: needs dx_masked and an active dropout site");
+  return layernorm_bwd_impl(x, a, dy, add_to, dx, da, db, rows, d, eps, dx_masked, rng, site, p_drop, stream);
 }
 
 extern "C" int tvae_colsum(const float* X, int ld, float* out, int M, int N, int accumulate, const uint32_t* rng,

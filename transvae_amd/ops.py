@@ -373,7 +373,42 @@ def layernorm_fwd(x2, a, b, eps=1e-6):
     return y
 
 
-def layernorm_bwd(x2, a, dy, add_to=None, eps=1e-6, a_param=None, b_param=None):
+# ---- residual-dropout masks applied where the gradient is PRODUCED -----------------------------------------------
+# The gradient arriving at the output of a SublayerConnection, y = x + dropout(sublayer(norm(x))), is needed twice with that
+# dropout's mask on it (data gradient and weight gradient of the sublayer's last projection).  It is written by the
+# LayerNorm backward of the NEXT sublayer (pre-norm: that LayerNorm reads y), so that kernel also writes the masked copy
+# (tvae_layernorm_bwd_masked: one more store stream) instead of both GEMMs regenerating the mask in their k-loops.
+#   _res_drop   output buffer of a sublayer (data_ptr) -> its residual Drop, noted by the forward pass
+#   _premasked  gradient buffer (data_ptr) -> (masked copy, site, the gradient tensor itself: keeps the address taken)
+# A sublayer only uses a masked copy made for exactly the tensor it receives and for its own site; if autograd summed
+# several gradients (an output with two consumers) the tensor is another one and the GEMMs mask while staging, as before.
+_res_drop, _premasked = {}, {}
+premask_stats = {"written": 0, "used": 0}
+
+
+def begin_step():
+    "forget the notes of earlier passes (VAEShell.train_step calls this before a forward pass)"
+    _res_drop.clear()
+    _premasked.clear()
+
+
+def _note_res_drop(y2, drop):
+    # (grad mode is off inside Function.forward, so it cannot be asked here; a Drop only exists in training mode)
+    if drop is not None and os.environ.get("TVAE_PREMASK", "1") == "1":
+        if len(_res_drop) > 256:
+            _res_drop.clear()
+        _res_drop[y2.data_ptr()] = drop
+
+
+def _take_premasked(dy2, drop):
+    hit = _premasked.pop(dy2.data_ptr(), None)
+    if hit is not None and drop is not None and hit[1] == drop.site and hit[0].shape == dy2.shape and hit[2] is not None:
+        premask_stats["used"] += 1
+        return hit[0]
+    return None
+
+
+def layernorm_bwd(x2, a, dy, add_to=None, eps=1e-6, a_param=None, b_param=None, up_drop=None):
     dx = torch.empty_like(x2)
     direct = _direct(a_param, b_param)
     if direct:
@@ -381,8 +416,18 @@ def layernorm_bwd(x2, a, dy, add_to=None, eps=1e-6, a_param=None, b_param=None):
     else:
         dab = torch.zeros((2, x2.shape[1]), device=x2.device, dtype=torch.float32)
         da, db = dab[0], dab[1]
-    call("tvae_layernorm_bwd", _p(x2), _p(a), _p(dy), _p(add_to), _p(dx), _p(da), _p(db),
-         x2.shape[0], x2.shape[1], eps, _stream())
+    if up_drop is not None and x2.shape[0] * x2.shape[1] < (1 << 32):
+        dxm = torch.empty_like(x2)
+        r, s, p = _drop_args(up_drop)
+        call("tvae_layernorm_bwd_masked", _p(x2), _p(a), _p(dy), _p(add_to), _p(dx), _p(dxm), _p(da), _p(db),
+             x2.shape[0], x2.shape[1], eps, r, s, p, _stream())
+        if len(_premasked) > 8:
+            _premasked.clear()
+        _premasked[dx.data_ptr()] = (dxm, up_drop.site, dx)
+        premask_stats["written"] += 1
+    else:
+        call("tvae_layernorm_bwd", _p(x2), _p(a), _p(dy), _p(add_to), _p(dx), _p(da), _p(db),
+             x2.shape[0], x2.shape[1], eps, _stream())
     if direct:
         _sink[0].done(a_param)
         _sink[0].done(b_param)
@@ -470,13 +515,14 @@ class LayerNormFn(torch.autograd.Function):
         y = layernorm_fwd(x2, a, b, eps)
         ctx.save_for_backward(x2, a)
         ctx.eps, ctx.P = eps, (a, b)
+        ctx.up_drop = _res_drop.get(x2.data_ptr())        # the norm after a stack of layers reads the last sublayer's output
         _note_use(a, b)
         return y.view(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
         x2, a = ctx.saved_tensors
-        dx, da, db = layernorm_bwd(x2, a, _c(dy).view(x2.shape), None, ctx.eps, *ctx.P)
+        dx, da, db = layernorm_bwd(x2, a, _c(dy).view(x2.shape), None, ctx.eps, *ctx.P, up_drop=ctx.up_drop)
         return dx.view(dy.shape), da, db, None
 
 
@@ -676,6 +722,8 @@ class AttnSublayerFn(torch.autograd.Function):
             v = linear_fwd(kv_in, Wv, bv)
         o, lse, _ = attn_fwd(q, k, v, B, h, Lq, Lk, dk, spec, drop_attn)
         y = linear_fwd(o, Wo, bo, residual=x2, drop=drop_res)
+        ctx.up_drop = _res_drop.get(x2.data_ptr())        # x is the output of the sublayer in front: its residual dropout
+        _note_res_drop(y, drop_res)
         ctx.save_for_backward(x2, n, kv_in if mem is not None else None, q, k, v, o, lse, ln_a, Wq, Wk, Wv, Wo)
         ctx.meta = (B, h, Lq, Lk, dk, spec, drop_attn, drop_res, eps, mem is not None)
         ctx.fuse = fuse
@@ -700,7 +748,7 @@ class AttnSublayerFn(torch.autograd.Function):
             dqkv = torch.empty((q.shape[0], 3 * d), device=q.device, dtype=torch.float32)
             attn_bwd(q, k, v, o, do, lse, B, h, Lq, Lk, dk, spec, drop_attn, out=(dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]))
             dn, ((dWq, dbq), (dWk, dbk), (dWv, dbv)) = _proj_fused_bwd(dqkv, n, (pWq, pWk, pWv), (pbq, pbk, pbv))
-            dx, da, db = layernorm_bwd(x2, ln_a, dn, add_to=dy2, eps=eps, a_param=pa, b_param=pb)
+            dx, da, db = layernorm_bwd(x2, ln_a, dn, add_to=dy2, eps=eps, a_param=pa, b_param=pb, up_drop=ctx.up_drop)
             return (dx.view(B, Lq, d), None, da, db, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo,
                     None, None, None, None, None)
         if fuse == 2 and _adjacent(pWk, pWv) and _adjacent(pbk, pbv):
@@ -715,7 +763,7 @@ class AttnSublayerFn(torch.autograd.Function):
             else:
                 _, ((dWk, dbk), (dWv, dbv)) = _proj_fused_bwd(dkv, kv_in, (pWk, pWv), (pbk, pbv), accumulate_into=dn)
                 dmem = None
-            dx, da, db = layernorm_bwd(x2, ln_a, dn, add_to=dy2, eps=eps, a_param=pa, b_param=pb)
+            dx, da, db = layernorm_bwd(x2, ln_a, dn, add_to=dy2, eps=eps, a_param=pa, b_param=pb, up_drop=ctx.up_drop)
             return (dx.view(B, Lq, d), dmem, da, db, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo,
                     None, None, None, None, None)
         dq, dkk, dv = attn_bwd(q, k, v, o, do, lse, B, h, Lq, Lk, dk, spec, drop_attn)
@@ -731,7 +779,7 @@ class AttnSublayerFn(torch.autograd.Function):
             linear_dgrad(dkk, Wk, out=dn, accumulate=True)
             linear_dgrad(dv, Wv, out=dn, accumulate=True)
             dmem = None
-        dx, da, db = layernorm_bwd(x2, ln_a, dn, add_to=dy2, eps=eps, a_param=pa, b_param=pb)
+        dx, da, db = layernorm_bwd(x2, ln_a, dn, add_to=dy2, eps=eps, a_param=pa, b_param=pb, up_drop=ctx.up_drop)
         return (dx.view(B, Lq, d), dmem, da, db, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo,
                 None, None, None, None, None)
 
@@ -747,6 +795,8 @@ class FFNSublayerFn(torch.autograd.Function):
         n = layernorm_fwd(x2, ln_a, ln_b, eps)
         hmid = linear_fwd(n, W1, b1, relu=True, drop=drop_ff, out=rows_buffer(n.shape[0], W1.shape[0], n.device))
         y = linear_fwd(hmid, W2, b2, residual=x2, drop=drop_res)
+        ctx.up_drop = _res_drop.get(x2.data_ptr())
+        _note_res_drop(y, drop_res)
         ctx.save_for_backward(x2, n, hmid, ln_a, W1, W2)
         ctx.meta = (drop_ff, drop_res, eps, shp)
         ctx.P = (ln_a, ln_b, W1, b1, W2, b2)
@@ -767,7 +817,7 @@ class FFNSublayerFn(torch.autograd.Function):
         dh = linear_dgrad(dym, W2, relumask=hmid, alpha=sc, a_drop=a_drop, out=rows_buffer(*hmid.shape, hmid.device))
         dW1, db1 = linear_wgrad(dh, n, W=pW1, b=pb1)
         dn = linear_dgrad(dh, W1)
-        dx, da, db = layernorm_bwd(x2, ln_a, dn, add_to=dy2, eps=eps, a_param=pa, b_param=pb)
+        dx, da, db = layernorm_bwd(x2, ln_a, dn, add_to=dy2, eps=eps, a_param=pa, b_param=pb, up_drop=ctx.up_drop)
         return dx.view(shp), da, db, dW1, db1, dW2, db2, None, None, None
 
 
@@ -1072,6 +1122,9 @@ def masked_grad(dy2, drop, force=False):
     output.  fp32 / bf16 kernels regenerate the keep-mask while staging (a_drop); the f32x3 kernel
     stages a k-major operand one row at a time, across the mask's hash groups, so there the mask is
     applied once by an elementwise pass and both GEMMs read the product."""
+    pre = _take_premasked(dy2, drop)
+    if pre is not None:                      # the LayerNorm backward that produced dy2 wrote the masked copy too
+        return pre, None
     streamed_bf16 = _state["dtype"] == BF16 and os.environ.get("TVAE_BF16_STREAM", "1") == "1"   # copies A as it is
     if drop is None or not (force or streamed_bf16 or F32X3 in (_state["dtype"], _state["wgrad"], _state["dgrad"])):
         return dy2, drop

@@ -635,6 +635,7 @@ class VAEShell():
         table = torch.empty((chunks, 5), device=dev, dtype=torch.float32)
         sink = dp.sink if dp is not None else ops.GradSink()
         sink.pending.clear()
+        ops.begin_step()
         with ops.direct_grads(sink):
             if self.params.get('FUSE_CHUNKS', True) and csize * chunks == data.shape[0]:
                 outs, grads = self._forward_backward(data, beta, eps, chunks, table, 0)

@@ -30,6 +30,26 @@ struct AttnArgs {
 
 constexpr float MASK_FILL = -1e9f;
 
+// -DTVAE_ATTN_STAMPS (tools/debug/attn_stamps.py builds such a library next to the real one): lane 0 of every wave of the
+// first 1024 workgroups records the shader clock at a few points of the kernel; tvae_debug_stamps copies them out.
+#ifdef TVAE_ATTN_STAMPS
+__device__ unsigned long long tvae_stamps[1024 * 4 * 16];
+#define STAMP(slot)                                                                                              \
+  do {                                                                                                           \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024)                                                            \
+      tvae_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (slot)] = __builtin_amdgcn_s_memtime();          \
+  } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
+// exp(x) for softmax weights, x <= 0 (or the -1e9 fill / -inf): one v_mul + one v_exp_f32 instead of expf's twelve
+// instructions (range reduction, ldexp, under/overflow selects).  The product x * log2(e) carries a relative error of
+// 2^-24 in the ARGUMENT, i.e. |x| 2^-24 relative in the weight: 6e-8 for the keys that dominate a row, 1e-6 for a key whose
+// weight is e^-17 of the row maximum -- below fp32 resolution of the row sum either way.  Forward and both backward
+// kernels use this one function, so the backward pass recomputes the forward's P bit for bit.
+__device__ inline float attn_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+
 // T[128][DK+4] <- src rows 0..nrows-1 (DK floats each), zero beyond.  Split in two so that the loads
 // of several tiles are all in flight before the first LDS write waits for them.
 template <int DK>
@@ -130,13 +150,34 @@ __device__ inline void mma_cols_x_acc(floatx16 (&out)[DK / 32], const float* __r
     }
     return;
   }
+  // The A operand comes from LDS one dword per MFMA.  Left to itself hipcc issues each pair's ds_read right behind the
+  // previous pair's MFMAs and waits for it in front of the next pair: one LDS latency exposed per two MFMAs.  Here the 16
+  // values of a half (8 tile rows) are all requested before the half's MFMAs, the second half's before the first half's
+  // MFMAs are issued (sched_barrier keeps the compiler from folding the groups back together).
+  constexpr int NUc = DK / 32;
+  float av[2][8][NUc];
+  auto fetch = [&](int half) {
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const float* p = &T[(row0 + crow(i, hh)) * LS + r];
+    for (int i = 0; i < 8; ++i) {
+      const float* p = &T[(row0 + crow(8 * half + i, hh)) * LS + r];
 #pragma unroll
-    for (int u = 0; u < DK / 32; ++u)
-      out[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[32 * u], breg[i], out[u], 0, 0, 0);
-  }
+      for (int u = 0; u < NUc; ++u) av[half][i][u] = p[32 * u];
+    }
+  };
+  auto run = [&](int half) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int u = 0; u < NUc; ++u)
+        out[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[half][i][u], breg[8 * half + i], out[u], 0, 0, 0);
+  };
+  fetch(0);
+  __builtin_amdgcn_sched_barrier(0);
+  fetch(1);
+  __builtin_amdgcn_sched_barrier(0);
+  run(0);
+  __builtin_amdgcn_sched_barrier(0);
+  run(1);
 }
 
 template <int DK>
@@ -221,16 +262,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   const int qs = qvalid ? qi : 0;
 
   float qreg[HALF];
+  STAMP(0);
   {
     TileRegs<DK> rk, rv;
     tile_issue<DK>(rk, a.k + (size_t)b * a.Lk * a.ldk + head * DK, a.ldk, a.Lk, tid);
     tile_issue<DK>(rv, a.v + (size_t)b * a.Lk * a.ldv + head * DK, a.ldv, a.Lk, tid);
     load_row_half<HALF>(qreg, a.q + ((size_t)b * a.Lq + qs) * a.ldq + head * DK + hh * HALF);
     load_key_bits(key_bits, a, b, tid);
+    STAMP(1);
     tile_commit<DK>(rk, Ks, a.Lk, tid);
     tile_commit<DK>(rv, Vs, a.Lk, tid);
+    STAMP(2);
   }
   __syncthreads();
+  STAMP(3);
 
   DropCfg dc = drop_cfg(a.rng, a.site, a.p);
   floatx16 st[4];
@@ -262,13 +307,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     if (!live.t[t]) continue;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      float p = expf(st[t][i] - mx);
+      float p = attn_exp(st[t][i] - mx);
       st[t][i] = p;
       sum += p;
     }
   }
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.f / sum;
+  STAMP(4);                                                   // scores and softmax statistics done
   const size_t prow = ((size_t)(b * a.h + head) * a.Lq + qi);
   if (qvalid && hh == 0 && a.lse_out) {
     // (row max, 1 / row sum) kept apart: with the -1e9 fill, max + log(sum) would round the log
@@ -310,7 +356,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     }
     mma_cols_x_acc<DK, BF>(oacc, Vs, 32 * t, hh, r, st[t]);
   }
+  STAMP(13);
   if (qvalid) store_rowmajor<DK>(a.o_out + ((size_t)b * a.Lq + qi) * a.ldo + head * DK, oacc, hh);
+  STAMP(14);
 }
 
 // ------------------------------------------------------------------------------- backward: dQ
@@ -401,7 +449,7 @@ void attn_bwd_dq_kernel(AttnArgs a) {
         float p = 0.f, dp = 0.f;
         if (off < nk) {
           const float sc = ((mw >> off) & 1U) ? pt[t][i] * a.scale : MASK_FILL;
-          p = expf(sc - row_mx) * row_ls;
+          p = attn_exp(sc - row_mx) * row_ls;
           dp = ((keep >> e) & 1U) ? dpt[t][i] * dc.scale : 0.f;
           psum += p;
           dsum += p * dp;
@@ -469,6 +517,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
   const size_t rows_pad = ((size_t)a.B * a.h * a.Lq + 3) & ~(size_t)3;
 
   // the workgroup's word from the dQ kernel (uniform: a scalar load), then every vector load of the prologue in one burst
+  STAMP(0);
   const uint32_t info = reinterpret_cast<const uint32_t*>(a.dsum)[rows_pad + 4 * (size_t)a.B * a.h * a.Lq + blockIdx.x];
   const int n_live = info & 7;
   const bool skip_ok = (info & 8U) != 0U;
@@ -499,8 +548,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
   const uint4 kw = *reinterpret_cast<const uint4*>(kwp);
   const uint8_t* kmp = a.key_mask ? a.key_mask + (size_t)b * a.Lk + ks : reinterpret_cast<const uint8_t*>(a.q);
   const uint8_t kmb = *kmp;
+  STAMP(1);
   tile_commit<DK>(rq, Qs, a.Lq, tid);
   tile_commit<DK>(rg, Gs, a.Lq, tid);
+  STAMP(2);
   if (tid < 128) {
     const bool ok = tid < a.Lq;
     stat_s[tid] = ok ? make_float4(st_mx, st_inv, st_ds, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -508,6 +559,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
   }
   const bool kbit = kvalid && (a.key_mask ? kmb != 0 : true);
   __syncthreads();
+  STAMP(3);
 
   floatx16 dkacc[NU], dvacc[NU];
 #pragma unroll
@@ -520,27 +572,39 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     if (skip_ok && __ballot(lane_live) == 0ULL) continue;
     floatx16 s = mma_rows_x_reg<DK, BF>(Qs, 32 * t + r, hh, kreg);
     floatx16 dp = mma_rows_x_reg<DK, BF>(Gs, 32 * t + r, hh, vreg);
+    // Per element: the query's {row max, 1 / row sum, dsum} and keep word come from LDS.  They are fetched eight queries at
+    // a time BEFORE the arithmetic, which is branch-free (selects): with the reads inside `if (valid)` blocks every element
+    // waited for its own LDS round trip (16 exposed latencies per tile, a third of the kernel's time in the stamps).
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      int qi = 32 * t + crow(i, hh);
-      float pt = 0.f, ds = 0.f;
-      if (kvalid && qi < a.Lq) {
-        bool m = kbit;
-        if (a.causal) m = m && (key <= qi);
-        if (GENERIC && a.full_mask) m = m && (a.full_mask[((size_t)b * a.Lq + qi) * a.Lk + key] != 0);
-        const float4 st = stat_s[qi];
-        float sc = m ? s[i] * a.scale : MASK_FILL;
-        float p = expf(sc - st.x) * st.y;
-        float ksc = ((keep_s[qi][kt] >> r) & 1U) ? dc.scale : 0.f;
-        pt = p * ksc;
-        if (m) ds = p * (dp[i] * ksc - st.z) * a.scale;
+    for (int half = 0; half < 2; ++half) {
+      float4 stv[8];
+      uint32_t kwv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int qi = 32 * t + crow(8 * half + j, hh);        // < 128: rows past Lq hold zeros / all-ones
+        stv[j] = stat_s[qi];
+        kwv[j] = keep_s[qi][kt];
       }
-      s[i] = pt;
-      dp[i] = ds;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = 8 * half + j, qi = 32 * t + crow(i, hh);
+        const bool valid = kvalid && qi < a.Lq;
+        bool m = kbit && (!a.causal || key <= qi);
+        if (GENERIC && a.full_mask) m = m && valid && (a.full_mask[((size_t)b * a.Lq + qi) * a.Lk + key] != 0);
+        const float sc = m ? s[i] * a.scale : MASK_FILL;
+        const float p = attn_exp(sc - stv[j].x) * stv[j].y;
+        const float ksc = ((kwv[j] >> r) & 1U) ? dc.scale : 0.f;
+        const float dsv = p * (dp[i] * ksc - stv[j].z) * a.scale;
+        s[i] = valid ? p * ksc : 0.f;
+        dp[i] = (valid && m) ? dsv : 0.f;
+      }
     }
+    STAMP(4 + 2 * (t - tq0));            // S, dP and the softmax arithmetic of this query tile are done
     mma_cols_x_acc<DK, BF>(dvacc, Gs, 32 * t, hh, r, s);
     mma_cols_x_acc<DK, BF>(dkacc, Qs, 32 * t, hh, r, dp);
+    STAMP(5 + 2 * (t - tq0));            // its dV / dK MFMAs are issued
   }
+  STAMP(12);
   if (share > 1) {                       // workgroup-uniform
     // waves that share a key tile: the first of them (the owner) adds the others' partial sums, in wave order
     const int sub = wave % share;        // 0 = owner
@@ -586,10 +650,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
         }
     }
   }
+  STAMP(13);
   if (kvalid) {
     store_rowmajor<DK>(a.dk + ((size_t)b * a.Lk + key) * a.lddk + head * DK, dkacc, hh);
     store_rowmajor<DK>(a.dv + ((size_t)b * a.Lk + key) * a.lddv + head * DK, dvacc, hh);
   }
+  STAMP(14);
 }
 
 typedef void (*AttnKernel)(AttnArgs);
@@ -615,6 +681,12 @@ int check_common(const char* who, int B, int h, int Lq, int Lk, int dk, const in
 }
 
 }  // namespace
+
+#ifdef TVAE_ATTN_STAMPS
+extern "C" int tvae_debug_stamps(unsigned long long* host_out, int n) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(tvae_stamps), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int tvae_attn_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
                              float* lse, float* p_out, const uint8_t* key_mask, const uint8_t* full_mask, int causal,

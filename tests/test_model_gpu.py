@@ -205,7 +205,7 @@ def test_premasked_residual_gradients_equal_masks_regenerated_in_the_gemms(monke
     """Training mode, dropout on.  The gradient at a sublayer's output is written by the next LayerNorm backward, which
     also writes it with the sublayer's residual-dropout mask applied (tvae_layernorm_bwd_masked); the sublayer's two
     gradient products then read that copy instead of regenerating the mask while staging.  Same seed, both ways: the
-    same losses bit for bit and the same gradients (weight gradients are summed with atomics: 2e-6)."""
+    same losses and the same gradients (weight gradients are summed with atomics: 2e-6)."""
     from transvae_amd import ops, synth
     g = load("step_4x256_zinc")
     toks = torch.from_numpy(g["tokens"].astype(np.int64))
@@ -225,7 +225,7 @@ def test_premasked_residual_gradients_equal_masks_regenerated_in_the_gemms(monke
         assert used == (0 if flag == "0" else 17), used        # every one of the 17 sublayers of the model took the masked copy
         losses[flag] = [float(o.detach()) for o in out]
         grads[flag] = {k: p.grad.detach().clone() for k, p in vae.model.named_parameters()}
-    assert losses["0"] == losses["1"]
+    np.testing.assert_allclose(losses["1"], losses["0"], rtol=1e-6)     # the loss kernel sums its blocks with atomics: order, not arithmetic
     for k in grads["0"]:
         if float(grads["0"][k].norm()) < 1e-7:       # key-projection biases: the true gradient is exactly zero, both are rounding noise
             assert float(grads["1"][k].norm()) < 1e-7, k

@@ -123,12 +123,14 @@ def roofline_decode_of(n):
     fn, nbytes = decode_attn_launch(n)
     t = time_launches(fn, 20)
     traffic, traffic_source = None, None
-    pmc = os.path.join(ROOT, "profiles", "r2_decode_attn_pmc.json")
-    if os.path.exists(pmc):
-        rec = json.load(open(pmc))
-        if rec.get("shape", {}).get("n") == n:
-            traffic = rec["traffic_bytes_per_launch"]
-            traffic_source = "profiles/r2_decode_attn_pmc.json (rocprofv3 --pmc passes, tools/pmc_decode.sh; the kernel is unchanged since), not measured in this run"
+    for tag in ("r3", "r2"):
+        pmc = os.path.join(ROOT, "profiles", "%s_decode_attn_pmc.json" % tag)
+        if os.path.exists(pmc):
+            rec = json.load(open(pmc))
+            if rec.get("shape", {}).get("n") == n:
+                traffic = rec["traffic_bytes_per_launch"]
+                traffic_source = "profiles/%s_decode_attn_pmc.json (rocprofv3 --pmc passes, tools/pmc_decode.sh), not measured in this run" % tag
+                break
     return {"bound": "hbm", "achieved": nbytes / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / t / 1e9 / 8000.0,
             "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes": nbytes, "launch_us": t * 1e6,
             "kernel": "decode_attn_kernel<64>: one query per (molecule, head) over 63 cached fp32 K and V rows, %d molecules "

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 DT=$1; TAG=$2
 cd /tmp || exit 1
 rm -rf "$R/gpurun_out/prof_$TAG"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_$TAG" -- python3 "$R/bench.py" --dtype $DT --steps 3 --warmup 1 --no-cpu-baseline --no-decode --no-extra-modes --no-roofline > "$R/gpurun_out/prof_${TAG}_bench.json" 2> "$R/gpurun_out/prof_${TAG}.err" || { tail -5 "$R/gpurun_out/prof_${TAG}.err"; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_$TAG" -- python3 "$R/bench.py" --dtype $DT --steps 3 --warmup 1 --no-cpu-baseline --no-decode --no-extra-modes --no-roofline --no-config1 > "$R/gpurun_out/prof_${TAG}_bench.json" 2> "$R/gpurun_out/prof_${TAG}.err" || { tail -5 "$R/gpurun_out/prof_${TAG}.err"; exit 1; }
 cd "$R" && python3 - "$TAG" <<'P'
 import csv, glob, sys
 tag = sys.argv[1]

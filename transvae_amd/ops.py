@@ -928,7 +928,9 @@ class ConvBottleneckFn(torch.autograd.Function):
         for li in (2, 1, 0):
             L, Lconv, Lp, Cin, Cout, k = ctx.metas[li]
             xin, conv = saved[2 * li], saved[2 * li + 1]
-            buf = torch.zeros(((k - 1) + B * L, Cout), device=dy.device, dtype=torch.float32)
+            # only the k-1 leading rows need zeroing: tvae_pool_relu_bwd writes every one of the B*L rows behind them
+            buf = torch.empty(((k - 1) + B * L, Cout), device=dy.device, dtype=torch.float32)
+            buf[:k - 1].zero_()
             dconv = buf[k - 1:]
             call("tvae_pool_relu_bwd", _p(conv), _p(dy), _p(dconv), B, L, Lconv, Cout, int(li == 2), _stream())
             dwp, grads[2 * li + 1], tr = _conv_wgrad(dconv, xin, B * L, Cin, Cout, k)
@@ -1022,7 +1024,8 @@ class DeconvBottleneckFn(torch.autograd.Function):
                 _, _, _, Lp, Cin, Cout, k, s, Q = ctx.metas[li]
                 # gradient of the pre-activation in the product's own layout (B*Lp, s*Cout) = rows (b, m s + r) x co:
                 # masked by the ReLU, zero on the rows outside [PAD, PAD + Lout) of every molecule
-                buf = torch.zeros((B * Lp * s + PAD, Cout), device=dup.device, dtype=torch.float32)
+                buf = torch.empty((B * Lp * s + PAD, Cout), device=dup.device, dtype=torch.float32)
+                buf[:PAD].zero_()                       # tvae_upsample_bwd writes all B*Lp*s rows behind the first PAD
                 call("tvae_upsample_bwd", _p(dup), _p(y[PAD:]), _p(buf[PAD:]), Lp * s, 0, B, Lout, Cout, d_stride, d_lpad,
                      d_Lup, _stream())
                 rows = B * Lp - (Q - 1)
@@ -1041,7 +1044,8 @@ class DeconvBottleneckFn(torch.autograd.Function):
                     dup, d_stride, d_lpad, d_Lup = dx, 1, 0, Lp              # input i of molecule b: row b Lp + i
             else:
                 _, _, _, Lup, Cin, Cout, k, s, lpad = ctx.metas[li]
-                buf = torch.zeros(((k - 1) + B * Lup, Cout), device=dup.device, dtype=torch.float32)
+                buf = torch.empty(((k - 1) + B * Lup, Cout), device=dup.device, dtype=torch.float32)
+                buf[:k - 1].zero_()                     # tvae_upsample_bwd writes all B*Lup rows behind them
                 dyr = buf[k - 1:]
                 call("tvae_upsample_bwd", _p(dup), _p(y), _p(dyr), Lup, 0, B, Lout, Cout, d_stride, d_lpad, d_Lup,
                      _stream())

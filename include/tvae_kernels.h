@@ -307,7 +307,9 @@ int tvae_loss_fwd_bwd(const int64_t* tokens, const float* logits, int ldl, const
  * is refused with TVAE_E_SHAPE.  Every call on a GPU shares that GPU's array (it is cleared on `stream` at the
  * start of each call), so two calls that overlap on ONE GPU -- different streams, or different threads -- race;
  * calls on one stream, or on different GPUs, do not.  The device that is current at the call must be the one
- * `stream` and the buffers belong to.
+ * `stream` and the buffers belong to.  The array's address is looked up on the FIRST call on each device (a symbol
+ * lookup, which may load the code object): make one ordinary, un-captured call per device before capturing a graph
+ * that contains this entry point.
  */
 #define TVAE_LOSS_STATIC_MAX_GROUPS 1024
 int tvae_loss_fwd_bwd_static(const int64_t* tokens, const float* logits, int ldl, const float* weights,

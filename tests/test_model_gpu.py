@@ -233,6 +233,40 @@ def test_premasked_residual_gradients_equal_masks_regenerated_in_the_gemms(monke
         assert rel_l2(grads["1"][k].cpu(), grads["0"][k].cpu()) < 2e-6, k
 
 
+def test_weight_gradients_on_the_second_stream_equal_the_single_stream_ones(monkeypatch):
+    """Inside direct_grads the weight-gradient products of the Linear layers run on a second stream beside the backward
+    pass (ops._side_begin); leaving the context joins it.  Same seed with TVAE_WGRAD_STREAM=0 and =1: the same gradients
+    (split-K sums use atomics: 2e-6), read right after the context without any host synchronisation in between; and the
+    second stream was really used (17 sublayers -> at least 30 products)."""
+    from transvae_amd import ops
+    g = load("step_4x256_zinc")
+    toks = torch.from_numpy(g["tokens"].astype(np.int64))
+    props, eps = torch.from_numpy(g["props"]), torch.from_numpy(g["eps"])
+    vae = build("4x256_zinc")
+    vae.model.train()
+    grads, launched = {}, {}
+    for flag in ("0", "1", "1"):                   # the second "1" pass starts from gradient buffers that exist already
+        monkeypatch.setenv("TVAE_WGRAD_STREAM", flag)
+        vae.model.zero_grad(set_to_none=(flag == "0"))
+        ops.seed_rng(torch.device("cuda:0"), 31)
+        ops.begin_step()
+        n_side = []
+        with ops.direct_grads(ops.GradSink()):
+            out, _ = run_chunk(vae, toks, props, eps, 0.02)
+            out[0].backward()
+            n_side.append(sum(e[1] for e in ops._side.values()))
+        launched[flag] = n_side[0]
+        assert sum(e[1] for e in ops._side.values()) == 0          # joined on the way out
+        grads[flag] = {k: p.grad.detach().clone() for k, p in vae.model.named_parameters()}
+        assert launched[flag] == (0 if flag == "0" else launched[flag]) and (flag == "0" or launched[flag] >= 30), launched
+        if flag == "1":
+            for k in grads["0"]:
+                if float(grads["0"][k].norm()) < 1e-7:
+                    assert float(grads["1"][k].norm()) < 1e-7, k
+                    continue
+                assert rel_l2(grads["1"][k].cpu(), grads["0"][k].cpu()) < 2e-6, k
+
+
 def test_accumulation_noam_adam_matches_reference():
     g = load("accum_1x128_zinc")
     vae = build("1x128_zinc", WARMUP_STEPS=int(g["warmup"]), BATCH_CHUNKS=2, BATCH_SIZE=12)

@@ -152,10 +152,11 @@ def _chk(t, name):
 
 # ----------------------------------------------------------------------------- raw launchers
 def gemm(A, lda, Bm, ldb, Cm, ldc, M, N, K, bias=None, residual=None, ldr=0, alpha=1.0, flags=0,
-         drop=None, dtype=None, a_rowsum=None):
+         drop=None, dtype=None, a_rowsum=None, stream=None):
     r, s, p = _drop_args(drop)
     call("tvae_gemm", _p(A), lda, _p(Bm), ldb, _p(Cm), ldc, M, N, K, _p(bias), _p(residual), ldr,
-         alpha, flags, r, s, p, _p(a_rowsum), _state["dtype"] if dtype is None else dtype, _stream())
+         alpha, flags, r, s, p, _p(a_rowsum), _state["dtype"] if dtype is None else dtype,
+         _stream() if stream is None else stream)
 
 
 # ---- direct gradient accumulation -------------------------------------------------------------
@@ -200,7 +201,50 @@ class direct_grads:
         return self.sink
 
     def __exit__(self, *exc):
+        join_side()
         _sink[0] = self.prev
+
+
+# ---- weight gradients on a second stream ------------------------------------------------------------------------------
+# With direct accumulation nothing in the backward pass READS a weight gradient: the split-K product only adds into param.grad.
+# So the weight-gradient GEMMs of the Linear layers go to a second stream that runs beside the backward pass proper: its tiles
+# (MFMA-bound, a few atomics at the end) fill the rounds a data-gradient GEMM leaves part empty and run under its epilogue, which
+# is all HBM traffic.  Measured (tools/debug/overlap_bench.py, MI355X, fp32): a (dgrad, wgrad) pair of a 63000-row 256 -> 256
+# layer 176 us back to back, 151 us on two streams; 256 -> 1024: 545 -> 514 us.  The second stream waits for an event of the
+# compute stream before every product (its operands are ready by then: the compute stream is in order) and the compute stream
+# waits for it ONCE: when the gradients are about to be read (direct_grads.__exit__, a data-parallel bucket, Adam).
+# Joining per product would give the gain back (182 us for the pair above).
+#   Operands read there are marked with record_stream: the caching allocator does not hand their memory to the compute stream
+# again before the second stream has passed the point where they were freed.
+# Stream priority makes no difference (29.9 / 30.0 ms per step at equal / raised priority).
+# TVAE_WGRAD_STREAM=0 launches everything on the compute stream, =2 uses the second stream in f32x3 mode too.
+_side = {}            # device index -> [stream, products launched since the last join]
+
+
+def _side_begin(*operands):
+    "stream pointer for a weight-gradient product that may run beside the backward pass, or None (compute stream)"
+    mode = os.environ.get("TVAE_WGRAD_STREAM", "1")
+    if _sink[0] is None or mode == "0" or not operands[0].is_cuda:
+        return None
+    if mode != "2" and _role_dtype("wgrad") == F32X3:     # measured: the 3 x bf16 kernel loses beside another GEMM (23.5 -> 24.0 ms/step)
+        return None
+    dev = operands[0].device
+    ent = _side.get(dev.index)
+    if ent is None:
+        ent = _side[dev.index] = [torch.cuda.Stream(device=dev), 0]
+    ent[0].wait_stream(torch.cuda.current_stream(dev))
+    for t in operands:
+        t.record_stream(ent[0])
+    ent[1] += 1
+    return C.c_void_p(ent[0].cuda_stream)
+
+
+def join_side():
+    "the compute stream of every device waits for the weight-gradient products launched beside it"
+    for idx, ent in _side.items():
+        if ent[1]:
+            torch.cuda.current_stream(idx).wait_stream(ent[0])
+            ent[1] = 0
 
 
 def _direct(*params):
@@ -333,10 +377,12 @@ def linear_dgrad(dy, W, out=None, accumulate=False, relumask=None, alpha=1.0, a_
     return out
 
 
-def linear_wgrad(dy, x, a_drop=None, want_bias=True, W=None, b=None):
+def linear_wgrad(dy, x, a_drop=None, want_bias=True, W=None, b=None, side=True):
     """dW[N,K] (+)= (dy*keepscale)^T x by split-K fp32 atomics, db[N] (+)= column sums of dy, the
     latter fused into the same launch.  With W (and b) given and direct accumulation active the
-    sums go straight into W.grad / b.grad and (None, None) is returned."""
+    sums go straight into W.grad / b.grad and (None, None) is returned; the product is then launched
+    on the second stream (_side_begin) unless `side` is False: the caller must not write dy or x
+    again before join_side()."""
     M, N = dy.shape
     K = x.shape[1]
     direct = _direct(W) and (not want_bias or _direct(b))
@@ -350,7 +396,8 @@ def linear_wgrad(dy, x, a_drop=None, want_bias=True, W=None, b=None):
     if dt == F32X3 and a_drop is not None:         # the 3xbf16 kernel cannot regenerate the mask of a k-major operand
         dy, a_drop = masked_grad(dy, a_drop, force=True)
     flags = GEMM_A_KMAJOR | GEMM_B_KMAJOR | GEMM_SPLITK | (GEMM_A_DROPMASK if a_drop is not None else 0)
-    gemm(dy, dy.stride(0), x, x.stride(0), dW, K, N, K, M, flags=flags, drop=a_drop, a_rowsum=db, dtype=dt)
+    gemm(dy, dy.stride(0), x, x.stride(0), dW, K, N, K, M, flags=flags, drop=a_drop, a_rowsum=db, dtype=dt,
+         stream=_side_begin(dy, x) if direct and side else None)
     if direct:
         _sink[0].done(W)
         if want_bias:
@@ -674,7 +721,7 @@ def _proj_fused_bwd(dcat, x_rows, Ws, bs, accumulate_into=None):
         gW, gb = [_sink[0].target(w) for w in Ws], [_sink[0].target(b) for b in bs]
         if _adjacent(*gW) and _adjacent(*gb):
             gemm(dcat, N, x_rows, x_rows.stride(0), _run(gW), K, N, K, M, flags=GEMM_A_KMAJOR | GEMM_B_KMAJOR | GEMM_SPLITK,
-                 a_rowsum=_run(gb), dtype=_role_dtype("wgrad"))
+                 a_rowsum=_run(gb), dtype=_role_dtype("wgrad"), stream=_side_begin(dcat, x_rows))
             for t in list(Ws) + list(bs):
                 _sink[0].done(t)
             grads = [(None, None)] * len(Ws)
@@ -1183,6 +1230,7 @@ class FusedAdam:
         self._hyper = (float(lr), 1.0 - b1 ** step, 1.0 - b2 ** step, float(grad_scale))
 
     def launch(self, zero_grad=False):
+        join_side()
         ptrs = self._ptr_table()
         call("tvae_adam_multi", _p(ptrs), _p(self.sizes), _p(self.chunk_tensor), _p(self.chunk_start),
              len(self.params), self.n_chunks, None, *self._hyper, self.betas[0], self.betas[1], self.eps,
@@ -1410,8 +1458,8 @@ class GRUStackFn(torch.autograd.Function):
         for l in range(n_layers):
             w_ih, w_hh, b_ih, b_hh = params[4 * l:4 * l + 4]
             xin, hbuf, _ = saved[3 * l:3 * l + 3]
-            grads[4 * l], grads[4 * l + 2] = linear_wgrad(dgi[l], xin, W=w_ih, b=b_ih)
-            grads[4 * l + 1], grads[4 * l + 3] = linear_wgrad(dgh[l], hbuf[:T * B], W=w_hh, b=b_hh)
+            grads[4 * l], grads[4 * l + 2] = linear_wgrad(dgi[l], xin, W=w_ih, b=b_ih, side=False)
+            grads[4 * l + 1], grads[4 * l + 3] = linear_wgrad(dgh[l], hbuf[:T * B], W=w_hh, b=b_hh, side=False)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = linear_dgrad(dgi[0], params[0]).view(T, B, I).transpose(0, 1).contiguous()

@@ -191,6 +191,8 @@ class DataParallel:
     def _launch(self, bi):
         s, e, _ = self.arena.buckets[bi]
         self._launched.add(bi)
+        from . import ops
+        ops.join_side()                  # weight-gradient products run on a second stream: the collective must see them done
         self._pending.append(_all_reduce_sum(self.arena.flat[s:e]))
 
     def arm(self):

@@ -129,11 +129,14 @@ int tvae_softmax_rows_bwd(const float* y, int ldy, const float* dy, int lddy, fl
 
 /*
  * Three-way bf16 split of an fp32 matrix w (rows x cols, row stride ldw) for the F32X3 arithmetic:
- * w = hi + mid + lo exactly to 2^-26, each a bf16.  out_n (rows, 3*cols): row r holds, for every group
- * of 8 consecutive columns, the 8 hi, the 8 mid and the 8 lo values back to back (cols % 8 == 0);
- * out_t (cols, 3*rows): the same for w^T (rows % 8 == 0).  Either may be NULL.  Lets tvae_gemm take an nn.Linear weight
- * (forward: out_n; data gradient: out_t) as a pre-split B operand (TVAE_GEMM_B_SPLIT3), so that the
- * kernel only splits the activation operand.  Weights change once per optimizer step.
+ * w = hi + mid + lo exactly to 2^-26, each a bf16.  out_n = the planes of w (rows n = matrix rows, contraction index
+ * k = columns; cols % 16 == 0), out_t = the planes of w^T (rows % 16 == 0); either may be NULL.  Layout, tile-major
+ * (csrc/gemm3_split.h): blocks of 64 rows x 16 k, block (n / 64, k / 16) at ((n / 64) * (K / 16) + k / 16) * 3072 elements,
+ * inside a block six pieces of 512 elements [k-half (k / 8) % 2][plane hi, mid, lo][row n % 64][8 values] -- one piece is
+ * what one LDS-DMA instruction of the streamed kernel moves.  Rows are padded with zeros to a multiple of 64, written by
+ * this call: out_n holds ceil64(rows) * 3 * cols elements, out_t ceil64(cols) * 3 * rows.  Lets tvae_gemm take an nn.Linear
+ * weight (forward: out_n; data gradient: out_t) as a pre-split B operand (TVAE_GEMM_B_SPLIT3, ldb = 3 * K of the split), so
+ * that the kernel only splits the activation operand.  Weights change once per optimizer step.
  */
 int tvae_split3(const float* w, int ldw, uint16_t* out_n, uint16_t* out_t, int rows, int cols, void* stream);
 

@@ -561,7 +561,8 @@ def test_sublayer_functions_match_oracle():
 
 # ---- fp32-accurate GEMM on the bf16 matrix cores (dtype f32x3) -------------------------------------
 @pytest.mark.parametrize("presplit", [False, True])
-@pytest.mark.parametrize("M,N,K", [(777, 256, 256), (1500, 1024, 256), (640, 256, 1024), (300, 260, 2304), (130, 132, 40)])
+@pytest.mark.parametrize("M,N,K", [(777, 256, 256), (1500, 1024, 256), (640, 256, 1024), (300, 260, 2304), (130, 132, 40),
+                                   (500, 144, 272), (129, 208, 48), (200, 64, 16), (200, 64, 32), (257, 768, 256)])
 def test_gemm_f32x3_is_as_accurate_as_fp32(M, N, K, presplit):
     """Every GEMM role (forward with bias/ReLU/residual, data gradient, weight gradient with the fused
     bias gradient) in 3xbf16-split arithmetic against an fp64 product: the error must be at the level

@@ -1,8 +1,9 @@
 #!/bin/bash
-# A/B of one environment switch on the train step, all three arithmetics, same box: bash tools/debug/ab_step.sh VAR
+# A/B of one environment switch on the train step, same box: bash tools/debug/ab_step.sh VAR [modes]
 VAR=${1:-TVAE_WGRAD_STREAM}
+MODES=${2:-"fp32 f32x3 bf16"}
 F="--steps 20 --warmup 3 --no-cpu-baseline --no-decode --no-extra-modes --no-roofline --no-config1"
-for m in fp32 f32x3 bf16; do
+for m in $MODES; do
   for v in 0 1 0 1; do
     export $VAR=$v
     timeout -k 10 120 python bench.py $F --dtype $m 2>/dev/null | python -c "

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtvae_hip.so")
-SOURCES = ["gemm.hip", "gemm3.hip", "gemm_dma.hip", "gemm_wide.hip", "rowops.hip", "attention.hip", "lossopt.hip", "dataprep.hip", "gru.hip"]
+SOURCES = ["gemm.hip", "gemm3.hip", "gemm3_dma.hip", "gemm_dma.hip", "gemm_wide.hip", "rowops.hip", "attention.hip", "lossopt.hip", "dataprep.hip", "gru.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 

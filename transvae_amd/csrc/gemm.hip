@@ -466,6 +466,7 @@ void tvae_gemm3_launch(const void* gp, int tiles, int splits, bool a_km, bool b_
                        hipStream_t s);   // gemm3.hip
 void tvae_gemm_dma_launch(const void* gp, bool bf16, hipStream_t s);   // gemm_dma.hip
 void tvae_gemm_wide_launch(const void* gp, int splits, bool km, hipStream_t s);   // gemm_wide.hip
+void tvae_gemm3_dma_launch(const void* gp, hipStream_t s);   // gemm3_dma.hip
 
 namespace {
 // TVAE_GEMM_WIDE: 0 never use the 128 x 160 kernel, 1 (default) for N in (128, 160], 2 for every N that wastes fewer columns on
@@ -476,6 +477,10 @@ int wide_mode() {
 }
 bool auto_split_enabled() {   // TVAE_GEMM_AUTOSPLIT=0 switches the tail-balance split of pure products off (read once)
   static bool on = [] { const char* e = getenv("TVAE_GEMM_AUTOSPLIT"); return !e || atoi(e) != 0; }();
+  return on;
+}
+bool x3_dma_enabled() {   // TVAE_GEMM3_DMA=0: f32x3 products against pre-split weights stay on the register-staged kernel (read once)
+  static bool on = [] { const char* e = getenv("TVAE_GEMM3_DMA"); return !e || atoi(e) != 0; }();
   return on;
 }
 bool fp32_dma_enabled() {   // TVAE_GEMM_DMA=1: exact-fp32 NT products take the LDS-DMA kernel too (experiment switch; read once)
@@ -565,12 +570,12 @@ static int gemm_impl(const float* A, int lda, const float* B, int ldb, float* C,
   // split-bf16 kernel: aligned operands only; a k-major A with the A-side dropout mask stays on the fp32 kernel
   const bool b_split = flags & TVAE_GEMM_B_SPLIT3;
   if (b_split) {
-    // B holds the bf16 planes written by tvae_split3 (per row: groups of 8 hi, 8 mid, 8 lo), ldb = 3 * Kb elements
+    // B holds the bf16 planes written by tvae_split3 (tile-major, gemm3_split.h), ldb = 3 * Kb elements
     TVAE_CHECK(dtype == TVAE_F32X3 && !b_km && !(flags & TVAE_GEMM_SPLITK) && !(a_km && drop), TVAE_E_SHAPE,
                "tvae_gemm: B_SPLIT3 needs dtype F32X3, an n-major B and no split-K");
-    TVAE_CHECK(ldb % 24 == 0 && ldb / 3 >= K && K % 8 == 0 && aligned16(B) && aligned16(A) && lda % 4 == 0 &&
+    TVAE_CHECK(ldb % 48 == 0 && ldb / 3 >= K && K % 16 == 0 && aligned16(B) && aligned16(A) && lda % 4 == 0 &&
                    (a_km ? M % 4 == 0 : true),
-               TVAE_E_SHAPE, "tvae_gemm: B_SPLIT3 needs K %% 8 == 0, ldb = 3*Kb with Kb %% 8 == 0, aligned operands");
+               TVAE_E_SHAPE, "tvae_gemm: B_SPLIT3 needs K %% 16 == 0, ldb = 3*Kb with Kb %% 16 == 0, aligned operands");
   }
   const bool x3 = batch == 1 && dtype == TVAE_F32X3 && (b_split || (aligned && !(a_km && drop)));
   int tiles = cdiv(M, BM) * cdiv(N, BN);
@@ -630,6 +635,12 @@ static int gemm_impl(const float* A, int lda, const float* B, int ldb, float* C,
     g.k_per_split = cdiv(K, 32) * 32;
   }
   hipStream_t s = (hipStream_t)stream;
+  if (x3 && b_split && !a_km && !drop && x3_dma_enabled()) {      // streamed kernel: no register staging, no LDS stores
+    g.k_per_split = K;
+    tvae_gemm3_dma_launch(&g, s);
+    TVAE_LAUNCH_CHECK("tvae_gemm");
+    return TVAE_OK;
+  }
   if (x3) {
     tvae_gemm3_launch(&g, tiles, splits, a_km, b_km, drop, b_split, s);
     TVAE_LAUNCH_CHECK("tvae_gemm");

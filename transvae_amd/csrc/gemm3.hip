@@ -22,6 +22,7 @@
 #include <type_traits>
 #include "common.h"
 #include "gemm_common.h"
+#include "gemm3_split.h"
 
 namespace {
 
@@ -31,8 +32,6 @@ constexpr int PLANE = BM * PITCH;                      // elements per plane
 constexpr int OPER = 3 * PLANE;                        // elements per operand tile (hi, mid, lo)
 constexpr int STAGE = 2 * OPER;                        // A + B
 static_assert(2 * STAGE * 2 >= EPILOGUE_LDS_FLOATS * 4, "epilogue slabs must fit the staging buffers");
-
-struct Stage8 { float v[8]; };
 
 // global -> registers: 8 consecutive k of row (row0 + tid/2 | tid%128) -- loads only; out-of-range
 // pieces read a clamped (valid) address and are zeroed in fix8, after the MFMAs of the current tile
@@ -82,32 +81,6 @@ __device__ inline void fix8(Stage8& s, int row0, int nrows, int k0, int kend, in
   for (int j = 0; j < 8; ++j) s.v[j] = (rok && (inside || k0 + kh + j < kend)) ? s.v[j] * ks[j] : 0.f;
 }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-__device__ inline uint32_t pack_bf16(float a, float b) {
-  // one v_cvt_pk_bf16_f32 (round to nearest even) for the pair; two scalar casts end up as two
-  // single conversions plus a re-pack
-  const f32x2 v = {a, b};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-}
-__device__ inline float bf16_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
-__device__ inline float bf16_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xFFFF0000U); }
-
-// 8 fp32 values -> the hi / mid / lo bf16 planes (pairs packed in 32-bit words)
-struct Split8 { uint32_t h[4], m[4], l[4]; };
-
-__device__ inline void split8(const Stage8& s, Split8& o) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float x0 = s.v[2 * q], x1 = s.v[2 * q + 1];
-    o.h[q] = pack_bf16(x0, x1);
-    const float r0 = x0 - bf16_lo(o.h[q]), r1 = x1 - bf16_hi(o.h[q]);        // exact
-    o.m[q] = pack_bf16(r0, r1);
-    const float t0 = r0 - bf16_lo(o.m[q]), t1 = r1 - bf16_hi(o.m[q]);        // exact
-    o.l[q] = pack_bf16(t0, t1);
-  }
-}
-
 // one 16-byte LDS store per plane
 template <bool KM>
 __device__ inline void store_planes(const Split8& o, unsigned short* __restrict__ T, int tid) {
@@ -118,9 +91,9 @@ __device__ inline void store_planes(const Split8& o, unsigned short* __restrict_
   *reinterpret_cast<uint4*>(dst + 2 * PLANE) = make_uint4(o.l[0], o.l[1], o.l[2], o.l[3]);
 }
 
-// pre-split B (TVAE_GEMM_B_SPLIT3): row n of B holds, for every group of 8 consecutive k, the 8 hi, the
-// 8 mid and the 8 lo bf16 values back to back (48 contiguous bytes = what one thread stages per
-// k-step), ldb = 3 * Kb elements -- three 16-byte loads per thread and k-step, no arithmetic
+// pre-split B (TVAE_GEMM_B_SPLIT3): the tile-major planes of gemm3_split.h, ldb = 3 * Kb elements (Kb = the K the weight was
+// split with, a multiple of 16) -- three 16-byte loads per thread and k-step, 1 KB apart, no arithmetic; consecutive row
+// threads read consecutive 16-byte pieces
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // native vector: HIP's uint4 struct went through scratch here
 struct Planes8 { u32x4 h, m, l; };
 
@@ -129,10 +102,10 @@ __device__ inline void load_planes(Planes8& o, const unsigned short* __restrict_
   const int row = tid >> 1, kh = (tid & 1) * 8;
   const int gn = n0 + row, gk = k0 + kh;
   const bool ok = gn < N && gk < kend;
-  const unsigned short* src = B + (size_t)(ok ? gn : 0) * ldb + (ok ? gk : 0) * 3;
+  const unsigned short* src = B + split_index(ok ? gn : 0, ok ? gk : 0, 0, ldb / 48);
   o.h = *reinterpret_cast<const u32x4*>(src);
-  o.m = *reinterpret_cast<const u32x4*>(src + 8);
-  o.l = *reinterpret_cast<const u32x4*>(src + 16);
+  o.m = *reinterpret_cast<const u32x4*>(src + SPLIT_PIECE);
+  o.l = *reinterpret_cast<const u32x4*>(src + 2 * SPLIT_PIECE);
 }
 __device__ inline void store_loaded_planes(const Planes8& o, unsigned short* __restrict__ T, int n0, int N, int k0, int kend,
                                            int tid) {
@@ -172,8 +145,8 @@ __device__ inline void load8_fast(Stage8& s, const float* __restrict__ base, int
 __device__ inline void load_planes_fast(Planes8& o, const unsigned short* __restrict__ base, uint32_t off) {
   const char* b = reinterpret_cast<const char*>(base);
   o.h = *reinterpret_cast<const u32x4*>(b + off);
-  o.m = *reinterpret_cast<const u32x4*>(b + off + 16);
-  o.l = *reinterpret_cast<const u32x4*>(b + off + 32);
+  o.m = *reinterpret_cast<const u32x4*>(b + off + 2 * SPLIT_PIECE);
+  o.l = *reinterpret_cast<const u32x4*>(b + off + 4 * SPLIT_PIECE);
 }
 __device__ inline void store_loaded_planes_fast(const Planes8& o, unsigned short* __restrict__ T, int tid) {
   unsigned short* dst = T + (tid >> 1) * PITCH + (tid & 1) * 8;
@@ -223,10 +196,10 @@ void gemm3_kernel(GemmArgs g) {
   // interior tile (workgroup-uniform): see load8_fast
   const bool fast_tile = a_rows_in && b_rows_in && nkt > 0 && ((kend - kbeg) % BK3 == 0);
   const uint32_t offA = fast_off<A_KM>(g.lda, tid);
-  const uint32_t offB = B_SPLIT ? (uint32_t)(((tid >> 1) * g.ldb + (tid & 1) * 24) * 2) : fast_off<B_KM>(g.ldb, tid);
+  const uint32_t offB = B_SPLIT ? (uint32_t)(split_index(tid >> 1, (tid & 1) * 8, 0, g.ldb / 48) * 2) : fast_off<B_KM>(g.ldb, tid);
   const float* baseA = A_KM ? g.A + (size_t)kbeg * g.lda + m0 : g.A + (size_t)m0 * g.lda + kbeg;
   const float* baseB = B_KM ? g.B + (size_t)kbeg * g.ldb + n0 : g.B + (size_t)n0 * g.ldb + kbeg;
-  const unsigned short* baseP = B16 + (size_t)n0 * g.ldb + (size_t)kbeg * 3;
+  const unsigned short* baseP = B16 + (B_SPLIT ? split_index(n0, kbeg, 0, g.ldb / 48) : 0);     // n0 % 128 == 0, kbeg % 16 == 0
   const size_t stepA = A_KM ? (size_t)BK3 * g.lda : (size_t)BK3, stepB = B_KM ? (size_t)BK3 * g.ldb : (size_t)BK3;
 
   // MFMAs of one k-step from LDS buffer `buf`; with a filler the split arithmetic of the NEXT k-step
@@ -261,7 +234,7 @@ void gemm3_kernel(GemmArgs g) {
       const int k0 = kbeg + step * BK3;
       if (FAST) {
         load8_fast<A_KM>(ra, baseA + step * stepA, g.lda, offA);
-        if (B_SPLIT) load_planes_fast(rp, baseP + (size_t)step * (3 * BK3), offB);
+        if (B_SPLIT) load_planes_fast(rp, baseP + (size_t)step * SPLIT_BLOCK, offB);
         else load8_fast<B_KM>(rb, baseB + step * stepB, g.ldb, offB);
       } else {
         load8<A_KM>(ra, g.A, g.lda, m0, g.M, k0, kend, tid);
@@ -370,15 +343,16 @@ void launch3(const GemmArgs& g, dim3 grid, hipStream_t s, bool drop) {
 }
 
 // ---- tvae_split3: fp32 matrix -> hi/mid/lo bf16 planes, in the matrix's own orientation and transposed --
-// out_n[r][24*(c/8) + 8*p + c%8] and out_t[c][24*(r/8) + 8*p + r%8] (either may be null; C resp. R a
-// multiple of 8): what TVAE_GEMM_B_SPLIT3 consumes as the
-// weight operand of the forward (W) and of the data gradient (W^T).  32x32 tiles through LDS so that
-// both outputs are written along their contiguous dimension.
+// out_n = planes of w (rows r, contraction index c) and out_t = planes of w^T (rows c, contraction index r), both in the
+// tile-major layout of gemm3_split.h with their rows padded by zeros to a multiple of 64 (either may be null; C resp. R a
+// multiple of 16): what TVAE_GEMM_B_SPLIT3 consumes as the weight operand of the forward (W) and of the data gradient (W^T).
+// 32x32 tiles through LDS so that both outputs are written in runs of 8 elements.
 __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ w, int ldw, unsigned short* __restrict__ out_n,
                                                      unsigned short* __restrict__ out_t, int R, int C) {
   __shared__ unsigned short tile[3][32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
   const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int Rpad = (R + 63) & ~63, Cpad = (C + 63) & ~63;       // the grid covers the padded extents
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = r0 + ty + 8 * i, c = c0 + tx;
@@ -389,9 +363,9 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ w
     const float r2 = r1 - __builtin_bit_cast(float, (uint32_t)m << 16);
     const unsigned short l = __builtin_bit_cast(unsigned short, (__bf16)r2);
     tile[0][ty + 8 * i][tx] = h; tile[1][ty + 8 * i][tx] = m; tile[2][ty + 8 * i][tx] = l;
-    if (out_n && r < R && c < C) {
-      unsigned short* o = out_n + (size_t)r * (3 * C) + 24 * (c >> 3) + (c & 7);
-      o[0] = h; o[8] = m; o[16] = l;
+    if (out_n && r < Rpad && c < C) {                            // pad rows get the zeros computed above
+      unsigned short* o = out_n + split_index(r, c, 0, C >> 4);
+      o[0] = h; o[SPLIT_PIECE] = m; o[2 * SPLIT_PIECE] = l;
     }
   }
   __syncthreads();
@@ -399,9 +373,9 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ w
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = c0 + ty + 8 * i, r = r0 + tx;               // transposed: consecutive lanes -> consecutive r
-      if (r < R && c < C) {
-        unsigned short* o = out_t + (size_t)c * (3 * R) + 24 * (r >> 3) + (r & 7);
-        o[0] = tile[0][tx][ty + 8 * i]; o[8] = tile[1][tx][ty + 8 * i]; o[16] = tile[2][tx][ty + 8 * i];
+      if (r < R && c < Cpad) {
+        unsigned short* o = out_t + split_index(c, r, 0, R >> 4);
+        o[0] = tile[0][tx][ty + 8 * i]; o[SPLIT_PIECE] = tile[1][tx][ty + 8 * i]; o[2 * SPLIT_PIECE] = tile[2][tx][ty + 8 * i];
       }
     }
   }
@@ -412,9 +386,9 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ w
 extern "C" int tvae_split3(const float* w, int ldw, uint16_t* out_n, uint16_t* out_t, int rows, int cols, void* stream) {
   TVAE_CHECK(w && (out_n || out_t), TVAE_E_NULL, "tvae_split3: null pointer");
   TVAE_CHECK(rows > 0 && cols > 0 && ldw >= cols, TVAE_E_SHAPE, "tvae_split3: bad shape (%d x %d, ld %d)", rows, cols, ldw);
-  TVAE_CHECK((!out_n || cols % 8 == 0) && (!out_t || rows % 8 == 0), TVAE_E_SHAPE,
-             "tvae_split3: the contiguous dimension of each output must be a multiple of 8 (%d x %d)", rows, cols);
-  hipLaunchKernelGGL(split3_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0, (hipStream_t)stream, w, ldw, out_n,
+  TVAE_CHECK((!out_n || cols % 16 == 0) && (!out_t || rows % 16 == 0), TVAE_E_SHAPE,
+             "tvae_split3: the contraction dimension of each output must be a multiple of 16 (%d x %d)", rows, cols);
+  hipLaunchKernelGGL(split3_kernel, dim3(cdiv(cols, 64) * 2, cdiv(rows, 64) * 2), dim3(256), 0, (hipStream_t)stream, w, ldw, out_n,
                      out_t, rows, cols);
   TVAE_LAUNCH_CHECK("tvae_split3");
   return TVAE_OK;

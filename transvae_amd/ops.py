@@ -217,16 +217,14 @@ class direct_grads:
 #   Operands read there are marked with record_stream: the caching allocator does not hand their memory to the compute stream
 # again before the second stream has passed the point where they were freed.
 # Stream priority makes no difference (29.9 / 30.0 ms per step at equal / raised priority).
-# TVAE_WGRAD_STREAM=0 launches everything on the compute stream, =2 uses the second stream in f32x3 mode too.
+# (f32x3 mode: 23.5 -> 24.0 ms per step while every product ran on the register-staged 3 x bf16 kernel at 74 KB of LDS, 23.2 -> 22.9
+# since the forward / data-gradient products have the streamed kernel.)  TVAE_WGRAD_STREAM=0 launches everything on the compute stream.
 _side = {}            # device index -> [stream, products launched since the last join]
 
 
 def _side_begin(*operands):
     "stream pointer for a weight-gradient product that may run beside the backward pass, or None (compute stream)"
-    mode = os.environ.get("TVAE_WGRAD_STREAM", "1")
-    if _sink[0] is None or mode == "0" or not operands[0].is_cuda:
-        return None
-    if mode != "2" and _role_dtype("wgrad") == F32X3:     # measured: the 3 x bf16 kernel loses beside another GEMM (23.5 -> 24.0 ms/step)
+    if _sink[0] is None or os.environ.get("TVAE_WGRAD_STREAM", "1") == "0" or not operands[0].is_cuda:
         return None
     dev = operands[0].device
     ent = _side.get(dev.index)
@@ -284,11 +282,12 @@ def weights_changed():
 
 
 def _split_weight(W, dtype=None):
-    """(planes of W (N, 3K), planes of W^T (K, 3N)) as int16 tensors, or None if W does not qualify."""
+    """(planes of W, planes of W^T) as int16 tensors in tvae_split3's tile-major layout (rows padded to a multiple of 64:
+    (ceil64(N), 3K) and (ceil64(K), 3N) elements), or None if W does not qualify."""
     if (_state["dtype"] if dtype is None else dtype) != F32X3 or not isinstance(W, torch.nn.Parameter) or W.dim() != 2 or not W.is_contiguous():
         return None
     N, K = W.shape
-    if N % 8 or K % 8:
+    if N % 16 or K % 16:
         return None
     # the planes live ON the parameter object: a cache keyed by address would hand a new model that
     # reuses a freed address the old model's (possibly smaller) buffers
@@ -296,11 +295,12 @@ def _split_weight(W, dtype=None):
     hit = getattr(W, "_tvae_split3", None)
     if hit is not None and hit[0] == stamp:
         return hit[1], hit[2]
-    if hit is not None and hit[1].shape == (N, 3 * K) and hit[1].device == W.device:
+    pad = lambda n: (n + 63) // 64 * 64
+    if hit is not None and hit[1].shape == (pad(N), 3 * K) and hit[1].device == W.device:
         wn, wt = hit[1], hit[2]                       # same shape: reuse the buffers
     else:
-        wn = torch.empty((N, 3 * K), device=W.device, dtype=torch.int16)
-        wt = torch.empty((K, 3 * N), device=W.device, dtype=torch.int16)
+        wn = torch.empty((pad(N), 3 * K), device=W.device, dtype=torch.int16)      # the kernel writes the pad rows (zeros) too
+        wt = torch.empty((pad(K), 3 * N), device=W.device, dtype=torch.int16)
     call("tvae_split3", _p(W), K, _p(wn), _p(wt), N, K, _stream())
     W._tvae_split3 = (stamp, wn, wt)
     return wn, wt

@@ -222,6 +222,37 @@ class direct_grads:
 _side = {}            # device index -> [stream, products launched since the last join]
 
 
+def _runs_beside(main, cand, cycles=300000):
+    """True if a kernel on `cand` overlaps one on `main`.  HIP maps its streams onto a few hardware queues (GPU_MAX_HW_QUEUES,
+    4 here) in creation order; two streams on one queue run strictly one after the other.  Which pool stream shares the
+    compute stream's queue depends on what else the process created first (RCCL's streams under data parallelism: measured,
+    the first pool stream then serialised with the compute stream and the step LOST 1 ms), so it is measured: two spin
+    kernels of `cycles`, one per stream, take about one spin when the queues differ and two when they do not."""
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    cand.wait_stream(main)
+    ev[0].record(main)
+    torch.cuda._sleep(cycles)
+    ev[1].record(main)
+    with torch.cuda.stream(cand):
+        torch.cuda._sleep(cycles)
+    main.wait_stream(cand)
+    ev[2].record(main)
+    ev[2].synchronize()
+    return ev[0].elapsed_time(ev[2]) < 1.5 * ev[0].elapsed_time(ev[1])
+
+
+def _pick_side_stream(dev):
+    main = torch.cuda.current_stream(dev)
+    first = None
+    for _ in range(6):
+        cand = torch.cuda.Stream(device=dev)
+        if first is None:
+            first = cand
+        if _runs_beside(main, cand):
+            return cand
+    return first
+
+
 def _side_begin(*operands):
     "stream pointer for a weight-gradient product that may run beside the backward pass, or None (compute stream)"
     if _sink[0] is None or os.environ.get("TVAE_WGRAD_STREAM", "1") == "0" or not operands[0].is_cuda:
@@ -229,12 +260,18 @@ def _side_begin(*operands):
     dev = operands[0].device
     ent = _side.get(dev.index)
     if ent is None:
-        ent = _side[dev.index] = [torch.cuda.Stream(device=dev), 0]
+        ent = _side[dev.index] = [_pick_side_stream(dev), 0]
     ent[0].wait_stream(torch.cuda.current_stream(dev))
     for t in operands:
         t.record_stream(ent[0])
     ent[1] += 1
     return C.c_void_p(ent[0].cuda_stream)
+
+
+def side_stream(device):
+    "the weight-gradient stream of `device` if one is in use (products launched since the last join), else None"
+    ent = _side.get(device.index) if device.type == "cuda" else None
+    return ent[0] if ent is not None and ent[1] else None
 
 
 def join_side():

@@ -192,8 +192,19 @@ class DataParallel:
         s, e, _ = self.arena.buckets[bi]
         self._launched.add(bi)
         from . import ops
-        ops.join_side()                  # weight-gradient products run on a second stream: the collective must see them done
-        self._pending.append(_all_reduce_sum(self.arena.flat[s:e]))
+        buf = self.arena.flat[s:e]
+        side = ops.side_stream(buf.device)
+        if side is None:
+            self._pending.append(_all_reduce_sum(buf))
+            return
+        # Weight-gradient products run on a second stream (ops._side_begin).  The collective must see them done, the backward
+        # pass need not: the all-reduce is issued FROM that stream (which first waits for what the compute stream has
+        # launched: LayerNorm / embedding / conv gradients of the bucket), so RCCL's stream orders itself behind both and
+        # the compute stream is not held up.  Joining the compute stream here instead cost 1.9 ms per step (4 buckets,
+        # each waiting out the weight gradients still queued: 32.1 vs 30.2 ms single-process on one box).
+        side.wait_stream(torch.cuda.current_stream(buf.device))
+        with torch.cuda.stream(side):
+            self._pending.append(_all_reduce_sum(buf))
 
     def arm(self):
         "call before the backward of the last accumulation chunk"

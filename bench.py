@@ -91,7 +91,7 @@ def roofline_of(mode, M, N, K):
                                   "kernel and shape (tools/pmc_traffic.sh), not measured in this run" % (tag, mode))
                 break
     kern = {"fp32": "gemm_kernel (v_mfma_f32_32x32x2_f32)", "bf16": "gemm_dma_kernel (v_mfma_f32_32x32x16_bf16; fp32 activations and bf16 weights streamed to LDS by LDS-DMA)",
-            "f32x3": "gemm3_kernel (6 x v_mfma_f32_32x32x16_bf16 per fp32 product block; peak = bf16 peak / 6)"}[mode]
+            "f32x3": "gemm3_dma_kernel (6 x v_mfma_f32_32x32x16_bf16 per fp32 product block, fp32 activations and pre-split weight planes streamed to LDS by LDS-DMA; peak = bf16 peak / 6; a bare loop of its fragment reads and MFMAs reaches 0.70 of that peak: profiles/r3_mfma_x3_bare_loop.txt)"}[mode]
     return {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[mode], "unit": "TFLOP/s",
             "frac": ach / PEAK_TFLOPS[mode], "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_bytes": 4.0 * (M * K + N * K + N + M * N),

@@ -3,6 +3,7 @@
 around ops.gemm, each launch timed with events (synchronised: durations are those of isolated warm launches), aggregated
 by shape with the achieved TFLOP/s.  python tools/gemm_shapes_step.py [dtype]"""
 import sys, os, collections
+os.environ["TVAE_WGRAD_STREAM"] = "0"      # isolated launches: the weight gradients stay on the compute stream, where the events are
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench

@@ -176,7 +176,7 @@ def test_bench_prints_the_contract_line():
 
 def test_bench_roofline_only():
     out = _run_bench("--roofline-only", "--dtype", "f32x3")
-    assert list(out) == ["roofline"] and "gemm3_kernel" in out["roofline"]["kernel"]
+    assert list(out) == ["roofline"] and "gemm3_dma_kernel" in out["roofline"]["kernel"]
 
 
 def test_bench_data_parallel_path_over_rccl_with_one_rank():

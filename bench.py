@@ -553,6 +553,7 @@ def main():
         out["decode_latents_total"] = args.decode_n
         out["decode_latents_per_gpu"] = share
         out["decode_slab"] = min(share, vae.DECODE_SLAB)
+        out["decode_streams"] = int(os.environ.get("TVAE_DECODE_STREAMS", "4"))      # pieces of a slab decoded side by side
         out["decode_seconds"] = td
         out["decode_scaling"] = "strong (the total is fixed: BASELINE.json config 4 decodes 1 M latents, sharded by rank)"
         out["decode_ids_bytes"] = int(ids.numel())                      # uint8 on the device

@@ -175,3 +175,22 @@ def test_decode_is_row_wise_at_slab_size_4x256():
     assert torch.equal(whole, again)
     perm = torch.randperm(n, generator=torch.Generator().manual_seed(14)).cuda()
     assert torch.equal(vae.greedy_decode(z[perm]), whole[perm])
+
+
+def test_decode_latents_slab_pieces_on_several_streams_equal_greedy_decode(monkeypatch):
+    """decode_latents decodes a slab as four quarter slabs whose step loops are issued in turn on four streams
+    (GreedyDecoder.run_iter).  Same tokens as greedy_decode on the whole input, as the two-stream form and as the one-stream
+    slab loop (TVAE_DECODE_STREAMS=1), with a ragged tail: a round of 4 x 3000, then 3000 + 3000 + 2500."""
+    vae = build("4x256_zinc")
+    vae.model.eval()
+    n = 20500
+    z = torch.randn(n, 128, generator=torch.Generator().manual_seed(15)).cuda()
+    whole = vae.greedy_decode(z).to(torch.uint8)
+    four = vae.decode_latents(z, slab=12000)
+    assert four.dtype == torch.uint8 and torch.equal(four, whole)
+    assert torch.equal(vae.decode_latents(z, slab=12000), whole)         # again: the buffers of the first call are reused
+    monkeypatch.setenv("TVAE_DECODE_STREAMS", "2")
+    assert torch.equal(vae.decode_latents(z, slab=12000), whole)
+    monkeypatch.setenv("TVAE_DECODE_STREAMS", "1")
+    assert torch.equal(vae.decode_latents(z, slab=12000), whole)
+    assert not vae.model.training

@@ -87,6 +87,24 @@ class GreedyDecoder:
 
     def _steps(self, mem, key_mask, ids, start_id, cond_ids, max_len):
         "source K/V projections + max_len single-token steps; every launch goes to the current stream"
+        for ids in self._steps_iter(mem, key_mask, ids, start_id, cond_ids, max_len):
+            pass
+        return ids
+
+    def run_iter(self, z, key_mask, start_id, cond_ids=(), max_len=125):
+        """run() for a large slab as a generator: yields after the set-up and after every token step, the last value is the
+        (n, max_len) ids.  VAEShell.decode_latents resumes two of these in turn, each under its own stream, so that one
+        slab's attention over its K/V caches (HBM-bound) runs beside the other's projections (MFMA-bound).  The caller must
+        make the generator's stream current around every next()."""
+        spec = ops.MaskSpec(key_mask=key_mask)
+        mem = self.model.decoder.expand_memory(z, spec)
+        ids = None
+        for ids in self._steps_iter(mem, key_mask, None, start_id, tuple(int(t) for t in cond_ids), max_len):
+            yield None
+        yield ids[:, 1:]
+
+    def _steps_iter(self, mem, key_mask, ids, start_id, cond_ids, max_len):
+        "_steps as a generator (yields the ids buffer after the set-up and after every step)"
         model, h = self.model, self.h
         dec = model.decoder
         dev = mem.device
@@ -120,8 +138,9 @@ class GreedyDecoder:
         x = torch.empty((n, d), device=dev, dtype=torch.float32)
         qkv = torch.empty((n, 3 * d), device=dev, dtype=torch.float32)
         att = torch.empty((n, d), device=dev, dtype=torch.float32)
-        st = _stream()
+        yield ids
         for t in range(max_len):
+            st = _stream()               # a generator may be resumed under another stream context than it was started in
             call("tvae_embed_step", _p(ids), T, t, _p(lut), _p(pe), _p(x), n, d, vocab, st)
             cur = x
             for li, lyr in enumerate(layers):
@@ -148,4 +167,4 @@ class GreedyDecoder:
                 y = self._ln(cur, dec.norm)
                 logits = ops.linear_fwd(y, gen.weight, gen.bias)
                 call("tvae_argmax_next", _p(logits), n_cls, n_cls, _p(ids), T, t + 1, n, st)
-        return ids
+            yield ids

@@ -268,6 +268,25 @@ def _side_begin(*operands):
     return C.c_void_p(ent[0].cuda_stream)
 
 
+def second_stream(device):
+    "the second stream of `device` (created on first use; see _side_begin / _pick_side_stream)"
+    ent = _side.get(device.index)
+    if ent is None:
+        ent = _side[device.index] = [_pick_side_stream(device), 0]
+    return ent[0]
+
+
+_extra = {}
+
+
+def extra_stream(device, k):
+    "further streams of `device`, e.g. for decode_latents' slab pieces (taken from torch's pool as they come: not probed for their hardware queue)"
+    key = (device.index, k)
+    if key not in _extra:
+        _extra[key] = torch.cuda.Stream(device=device)
+    return _extra[key]
+
+
 def side_stream(device):
     "the weight-gradient stream of `device` if one is in use (products launched since the last join), else None"
     ent = _side.get(device.index) if device.type == "cuda" else None

@@ -849,7 +849,7 @@ class VAEShell():
         are MFMA-bound, and they overlap -- measured on 262,144 latents: 35.9 / 36.0 k molecules/s on one stream,
         36.5-37.4 k with two pieces, 37.3-37.8 k with three, 38.0 / 38.1 k with four (tools/debug/ab_decode.sh).
         TVAE_DECODE_STREAMS=1..4 sets the number; 1 decodes whole slabs one after the other on the current stream."""
-        slab = int(slab or self.DECODE_SLAB)
+        slab = int(slab or os.environ.get("TVAE_DECODE_SLAB") or self.DECODE_SLAB)
         dev = self._device()
         n = mem.shape[0]
         out = torch.empty((n, self.tgt_len), dtype=torch.uint8, device=dev)

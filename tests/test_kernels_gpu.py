@@ -598,6 +598,40 @@ def test_gemm_f32x3_is_as_accurate_as_fp32(M, N, K, presplit):
         assert e3 < max(2.0 * e1, 3e-7), (errs)
 
 
+@pytest.mark.parametrize("M,N,K", [(777, 256, 256), (500, 144, 272), (1030, 384, 64)])
+def test_gemm_f32x3_streamed_kernel_epilogues_match_the_fp32_kernel(M, N, K):
+    """The streamed f32x3 kernel (gemm3_dma.hip: pre-split nn.Parameter weight on the B side) has its own epilogue for its
+    row-wise wave layout.  Every fused form the model uses -- bias + ReLU + dropout, bias + dropout + residual, the data
+    gradient through a ReLU mask with alpha, the data gradient accumulated into its output -- against the exact-fp32 kernel
+    with the same flags (the dropout mask is a hash of the element index: identical), interior and edge tiles."""
+    from transvae_amd import ops
+    torch.manual_seed(M + N)
+    x = torch.randn(M, K, device=dev())
+    w = torch.nn.Parameter(torch.randn(N, K, device=dev()) * 0.05, requires_grad=False)
+    b = torch.randn(N, device=dev())
+    res = torch.randn(M, N, device=dev())
+    dy = torch.randn(M, N, device=dev())
+    saved = torch.randn(M, K, device=dev())
+    base = torch.randn(M, K, device=dev())
+    drop = ops.Drop(0.1, 21, ops.rng_state(dev()))
+    outs = {}
+    prev = ops.compute_dtype()
+    try:
+        for mode in ("fp32", "f32x3"):
+            ops.set_compute_dtype(mode)
+            if mode == "f32x3":
+                assert ops._split_weight(w) is not None              # the streamed kernel's precondition
+            acc = base.clone()
+            ops.linear_dgrad(dy, w, out=acc, accumulate=True)
+            outs[mode] = [ops.linear_fwd(x, w, b, relu=True, drop=drop), ops.linear_fwd(x, w, b, residual=res, drop=drop),
+                          ops.linear_fwd(x, w, None), ops.linear_dgrad(dy, w, relumask=saved, alpha=1.25), acc]
+    finally:
+        ops.set_compute_dtype(prev)
+    for a, c in zip(outs["f32x3"], outs["fp32"]):
+        assert torch.equal(a == 0, c == 0)                           # the same elements dropped / masked
+        assert rel_l2(a.cpu(), c.cpu()) < 1e-6
+
+
 # ---- streamed bf16 NT kernel (LDS-DMA, weight bf16 in memory) --------------------------------------------------
 @pytest.mark.parametrize("M,N,K", [(777, 256, 256), (1500, 1024, 256), (640, 256, 1024), (130, 136, 64), (12700, 768, 256),
                                    (50, 25 * 8, 32)])

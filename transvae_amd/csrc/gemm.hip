@@ -602,7 +602,8 @@ static int gemm_impl(const float* A, int lda, const float* B, int ldb, float* C,
     const int wm = wide_mode();
     const bool wide_n = wm >= 1 && N > 128 && (N <= 160 || (wm >= 2 && dtype == TVAE_F32 && cdiv(N, 160) * 160 < cdiv(N, 128) * 128));
     const int other = flags & ~(TVAE_GEMM_RELU | TVAE_GEMM_SPLITK | TVAE_GEMM_A_KMAJOR | TVAE_GEMM_B_KMAJOR | FLAG_VEC_EPILOGUE | FLAG_FAST_STAGE);
-    if (wide_n && batch == 1 && !bf16 && a_km == b_km && other == 0 && !residual && !a_rowsum && !drop && K >= 256 &&
+    const bool any_drop = rng && p_drop > 0.f;          // epilogue dropout or the A-side mask: the wide kernel has neither
+    if (wide_n && batch == 1 && !bf16 && a_km == b_km && other == 0 && !residual && !a_rowsum && !any_drop && K >= 256 &&
         (g.flags & FLAG_FAST_STAGE)) {
       int splits = 1;
       g.k_per_split = K;

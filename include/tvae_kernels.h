@@ -58,7 +58,7 @@ extern "C" {
 #define TVAE_GEMM_ACCUM 2       /* C += v instead of C = v (plain read-modify-write) */
 #define TVAE_GEMM_A_KMAJOR 4    /* A(m,k) = A[k*lda + m]  (default A[m*lda + k]) */
 #define TVAE_GEMM_B_KMAJOR 8    /* B(k,n) = B[k*ldb + n]  (default B[n*ldb + k], i.e. nn.Linear weight) */
-#define TVAE_GEMM_SPLITK 16     /* split K over grid.z, fp32 atomicAdd into C (C must be initialised) */
+#define TVAE_GEMM_SPLITK 16     /* split K over grid.z, fp32 atomicAdd into C (C must be initialised); bias / alpha only: ReLU, residual and output dropout are refused */
 #define TVAE_GEMM_RELUMASK 64   /* v = residual[m,n] > 0 ? v : 0 (`residual` is the saved activation, not added) */
 #define TVAE_GEMM_B_SPLIT3 128  /* dtype F32X3 only: B points at bf16 planes written by tvae_split3, ldb = 3*Kb in bf16 elements */
 #define TVAE_GEMM_B_BF16 256    /* dtype BF16 only: B points at bf16 values (N, ldb) written by tvae_cast_bf16; row-major A, K % 32 == 0 */

@@ -83,6 +83,28 @@ def test_gemm_wide_tile_nt(M, N, K, monkeypatch):
     assert rel_l2(out.cpu(), 0.5 * (A @ w.T) + b) < TOL
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 148, 512), (300, 200, 1024), (640, 160, 768)])
+def test_gemm_output_dropout_survives_every_dispatch(M, N, K):
+    """Output dropout is signalled by (rng, p) alone, not by a flag.  Launches that would otherwise take the wide-tile kernel
+    (N in (128, 160]) or the tail-balance K split (a pure product of few tiles with K >= 512) -- neither can drop -- must
+    stay on the kernel that does: ~10 % of the outputs are zero, the rest are the plain product times 1 / P(keep), and split-K
+    with output dropout is refused."""
+    from transvae_amd import ops, _lib
+    x, w = rnd(M, K, seed=31), rnd(N, K, seed=32, scale=0.1)
+    drop = ops.Drop(0.1, 17, ops.rng_state(dev()))
+    plain = ops.linear_fwd(g32(x), g32(w), None)
+    dropped = ops.linear_fwd(g32(x), g32(w), None, drop=drop)
+    kept = dropped != 0
+    frac = 1.0 - float(kept.float().mean())
+    assert 0.08 < frac < 0.12, frac
+    scale = float((dropped[kept] / plain[kept]).median())     # 1 / P(keep), P(keep) a multiple of 2^-16: 1.111119
+    assert abs(scale * 0.9 - 1.0) < 2e-5, scale
+    assert rel_l2(dropped[kept].cpu(), (plain[kept] * scale).cpu()) < TOL
+    out = torch.zeros((M, N), device=dev(), dtype=torch.float32)
+    with pytest.raises(_lib.TvaeError):
+        ops.gemm(g32(x), K, g32(w), K, out, N, M, N, K, flags=ops.GEMM_SPLITK, drop=drop)
+
+
 @pytest.mark.parametrize("M,N,K", [(2304, 160, 9999), (260, 148, 4100), (128, 160, 300)])
 def test_gemm_wide_tile_tn_splitk(M, N, K):
     "the weight-gradient form on the wide tile: both operands k-major, split-K atomics, a partial last k-step"

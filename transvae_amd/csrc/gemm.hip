@@ -506,8 +506,8 @@ static int gemm_impl(const float* A, int lda, const float* B, int ldb, float* C,
   TVAE_CHECK(!(rng && p_drop > 0.f) || ((long)M * N < (1L << 32) && (long)M * K < (1L << 32)), TVAE_E_SHAPE,
              "tvae_gemm: dropout index space exceeds 32 bits");
   if (flags & TVAE_GEMM_SPLITK)
-    TVAE_CHECK(!(flags & (TVAE_GEMM_RELU | 64)) && !residual, TVAE_E_SHAPE,
-               "tvae_gemm: split-K supports bias/alpha only");
+    TVAE_CHECK(!(flags & (TVAE_GEMM_RELU | 64)) && !residual && !(rng && p_drop > 0.f && !(flags & TVAE_GEMM_A_DROPMASK)), TVAE_E_SHAPE,
+               "tvae_gemm: split-K supports bias/alpha only (no ReLU, residual or output dropout: slabs are summed with atomics)");
 
   // float4 staging needs 16-byte aligned rows and a whole number of float4 along the
   // contiguous dimension (k for row-major operands, m/n for k-major ones)
@@ -520,7 +520,7 @@ static int gemm_impl(const float* A, int lda, const float* B, int ldb, float* C,
   // path of the weight gradients; the memset is asynchronous on the same stream), so the work items are several per CU.
   const bool bf16_ = dtype == TVAE_BF16;
   if (!(flags & ~(TVAE_GEMM_A_KMAJOR | TVAE_GEMM_B_KMAJOR)) && !bias && !residual && !a_rowsum && batch == 1 && !bf16_ &&
-      ldc == N && K >= 512 && auto_split_enabled()) {
+      !(rng && p_drop > 0.f) && ldc == N && K >= 512 && auto_split_enabled()) {
     const bool wide = wide_mode() >= 1 && N > 128 && N <= 160 && (flags & TVAE_GEMM_A_KMAJOR ? 1 : 0) == (flags & TVAE_GEMM_B_KMAJOR ? 1 : 0);
     const int t = wide ? cdiv(M, 128) * cdiv(N, 160) : cdiv(M, BM) * cdiv(N, BN);
     // Measured (profiles/r3_gemm_shapes_step_fp32.txt): worth it only where less than half of the CUs would have a tile at all

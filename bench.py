@@ -507,6 +507,7 @@ def main():
         "value_nonpad": world * nonpad * args.steps / dt, "nonpad_unit": "non-pad target tokens/s (secondary, SURVEY.md 8d: %d of "
                         "the %d target positions of a batch carry a token or <end>)" % (nonpad, args.batch * 126),
         "final_loss": last_loss,
+        "train_streams": 1 if os.environ.get("TVAE_WGRAD_STREAM", "1") == "0" else 2,   # weight-gradient GEMMs run beside the backward pass
         "data_parallel": dp_report,
         "train_algorithmic_tflops": world * args.batch * FLOP_PER_MOL_FWD_BWD * args.steps / dt / 1e12,
         "train_frac_of_mfma_peak": (args.batch * FLOP_PER_MOL_FWD_BWD * args.steps / dt / 1e12) / PEAK_TFLOPS[args.dtype],

@@ -93,8 +93,8 @@ class GreedyDecoder:
 
     def run_iter(self, z, key_mask, start_id, cond_ids=(), max_len=125):
         """run() for a large slab as a generator: yields after the set-up and after every token step, the last value is the
-        (n, max_len) ids.  VAEShell.decode_latents resumes two of these in turn, each under its own stream, so that one
-        slab's attention over its K/V caches (HBM-bound) runs beside the other's projections (MFMA-bound).  The caller must
+        (n, max_len) ids.  VAEShell.decode_latents resumes several of these in turn, each under its own stream, so that one
+        piece's attention over its K/V caches (HBM-bound) runs beside another's projections (MFMA-bound).  The caller must
         make the generator's stream current around every next()."""
         spec = ops.MaskSpec(key_mask=key_mask)
         mem = self.model.decoder.expand_memory(z, spec)

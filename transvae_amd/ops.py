@@ -293,6 +293,35 @@ def side_stream(device):
     return ent[0] if ent is not None and ent[1] else None
 
 
+class _side_block:
+    """`with _side_block(*operands) as on:` -- when `on`, everything launched (and allocated) inside goes to the second stream:
+    weight-gradient work of the conv / deconv bottleneck that ends in an add into param.grad and that nobody waits for.
+    Same rules as _side_begin (direct accumulation active, operands marked record_stream, joined before gradients are read)."""
+
+    def __init__(self, *operands):
+        self.operands, self.ctx = operands, None
+
+    def __enter__(self):
+        if not self.operands or os.environ.get("TVAE_CONV_WGRAD_STREAM", "1") != "1" or _side_begin(*self.operands) is None:
+            return False
+        self.ctx = torch.cuda.stream(_side[self.operands[0].device.index][0])
+        self.ctx.__enter__()
+        return True
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def _accumulate_direct(pairs):
+    "param.grad += g for (param, g) pairs on the current stream, and report the parameters' gradients complete"
+    for p, g_ in pairs:
+        _sink[0].target(p).add_(g_.view_as(p))
+    for p, _ in pairs:
+        _sink[0].done(p)
+
+
 def join_side():
     "the compute stream of every device waits for the weight-gradient products launched beside it"
     for idx, ent in _side.items():
@@ -1019,6 +1048,8 @@ class ConvBottleneckFn(torch.autograd.Function):
             cur, L = y, Lp
         ctx.save_for_backward(W0, W1, W2, *saved)
         ctx.metas, ctx.B = metas, B
+        ctx.P = (W0, b0, W1, b1, W2, b2)
+        _note_use(*ctx.P)
         return cur.view(B, -1)
 
     @staticmethod
@@ -1036,8 +1067,14 @@ class ConvBottleneckFn(torch.autograd.Function):
             buf[:k - 1].zero_()
             dconv = buf[k - 1:]
             call("tvae_pool_relu_bwd", _p(conv), _p(dy), _p(dconv), B, L, Lconv, Cout, int(li == 2), _stream())
-            dwp, grads[2 * li + 1], tr = _conv_wgrad(dconv, xin, B * L, Cin, Cout, k)
-            grads[2 * li] = _unpack_dw(dwp, W[li].shape, Cout, Cin, k, False, tr)
+            pW, pb = ctx.P[2 * li], ctx.P[2 * li + 1]
+            if _direct(pW, pb):          # nobody waits for these: weight gradient -> unpack -> add into param.grad beside the rest
+                with _side_block(dconv, xin):
+                    dwp, db_, tr = _conv_wgrad(dconv, xin, B * L, Cin, Cout, k)
+                    _accumulate_direct(((pW, _unpack_dw(dwp, W[li].shape, Cout, Cin, k, False, tr)), (pb, db_)))
+            else:
+                dwp, grads[2 * li + 1], tr = _conv_wgrad(dconv, xin, B * L, Cin, Cout, k)
+                grads[2 * li] = _unpack_dw(dwp, W[li].shape, Cout, Cin, k, False, tr)
             if li > 0 or ctx.needs_input_grad[0]:
                 wd = _pack_w(W[li], Cin, Cout, k, True)       # (Cin, k*Cout): wd[ci][j*Cout+co] = W[co][ci][k-1-j]
                 dy = _conv_dgrad(buf, B * L, Cout, wd, Cin, k)
@@ -1109,6 +1146,8 @@ class DeconvBottleneckFn(torch.autograd.Function):
         call("tvae_upsample_fwd", _p(src), src_rows, 0, _p(out), B, Lin, Cd, 1, 0, Lin, _stream())
         ctx.save_for_backward(W0, W1, W2, *saved)
         ctx.metas, ctx.B = metas, B
+        ctx.P = (W0, b0, W1, b1, W2, b2)
+        _note_use(*ctx.P)
         return out
 
     @staticmethod
@@ -1132,14 +1171,20 @@ class DeconvBottleneckFn(torch.autograd.Function):
                 call("tvae_upsample_bwd", _p(dup), _p(y[PAD:]), _p(buf[PAD:]), Lp * s, 0, B, Lout, Cout, d_stride, d_lpad,
                      d_Lup, _stream())
                 rows = B * Lp - (Q - 1)
-                dwp = torch.zeros((s * Cout, Q * Cin), device=dup.device, dtype=torch.float32)
-                dbp = torch.zeros((s * Cout,), device=dup.device, dtype=torch.float32)
-                gemm(buf, s * Cout, xin, Cin, dwp, Q * Cin, s * Cout, Q * Cin, rows,
-                     flags=GEMM_A_KMAJOR | GEMM_B_KMAJOR | GEMM_SPLITK, a_rowsum=dbp, dtype=_role_dtype("wgrad"))
-                dW = torch.empty_like(W[li])
-                db = torch.empty((Cout,), device=dup.device, dtype=torch.float32)
-                call("tvae_deconv_poly_pack", _p(dwp), _p(dW), _p(dbp), _p(db), Cin, Cout, k, s, 2, _stream())
-                grads[2 * li], grads[2 * li + 1] = dW, db
+                pW, pb = ctx.P[2 * li], ctx.P[2 * li + 1]
+                direct = _direct(pW, pb)
+                with _side_block(buf, xin) if direct else _side_block() as _on:      # (_side_block() without operands: plain)
+                    dwp = torch.zeros((s * Cout, Q * Cin), device=dup.device, dtype=torch.float32)
+                    dbp = torch.zeros((s * Cout,), device=dup.device, dtype=torch.float32)
+                    gemm(buf, s * Cout, xin, Cin, dwp, Q * Cin, s * Cout, Q * Cin, rows,
+                         flags=GEMM_A_KMAJOR | GEMM_B_KMAJOR | GEMM_SPLITK, a_rowsum=dbp, dtype=_role_dtype("wgrad"))
+                    dW = torch.empty_like(W[li])
+                    db = torch.empty((Cout,), device=dup.device, dtype=torch.float32)
+                    call("tvae_deconv_poly_pack", _p(dwp), _p(dW), _p(dbp), _p(db), Cin, Cout, k, s, 2, _stream())
+                    if direct:
+                        _accumulate_direct(((pW, dW), (pb, db)))
+                    else:
+                        grads[2 * li], grads[2 * li + 1] = dW, db
                 if li > 0 or ctx.needs_input_grad[0]:
                     wd, _ = _poly_pack(W[li], None, s, 1)                    # (Cin, Q*s*Cout)
                     dx = torch.empty((B * Lp, Cin), device=dup.device, dtype=torch.float32)
@@ -1152,8 +1197,14 @@ class DeconvBottleneckFn(torch.autograd.Function):
                 dyr = buf[k - 1:]
                 call("tvae_upsample_bwd", _p(dup), _p(y), _p(dyr), Lup, 0, B, Lout, Cout, d_stride, d_lpad, d_Lup,
                      _stream())
-                dwp, grads[2 * li + 1], tr = _conv_wgrad(dyr, xin, B * Lup, Cin, Cout, k)
-                grads[2 * li] = _unpack_dw(dwp, W[li].shape, Cout, Cin, k, True, tr)
+                pW, pb = ctx.P[2 * li], ctx.P[2 * li + 1]
+                if _direct(pW, pb):
+                    with _side_block(dyr, xin):
+                        dwp, db_, tr = _conv_wgrad(dyr, xin, B * Lup, Cin, Cout, k)
+                        _accumulate_direct(((pW, _unpack_dw(dwp, W[li].shape, Cout, Cin, k, True, tr)), (pb, db_)))
+                else:
+                    dwp, grads[2 * li + 1], tr = _conv_wgrad(dyr, xin, B * Lup, Cin, Cout, k)
+                    grads[2 * li] = _unpack_dw(dwp, W[li].shape, Cout, Cin, k, True, tr)
                 if li > 0 or ctx.needs_input_grad[0]:
                     wd = _pack_w(W[li], Cin, Cout, k, False)                 # wd[ci][j*Cout+co] = W[ci][co][j]
                     dup = _conv_dgrad(buf, B * Lup, Cout, wd, Cin, k)        # gradient of the zero-stuffed input

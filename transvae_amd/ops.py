@@ -719,7 +719,9 @@ class EmbedFn(torch.autograd.Function):
         direct = _direct(ctx.P)
         dlut = _sink[0].target(ctx.P) if direct else torch.zeros((vocab, d), device=dout.device, dtype=torch.float32)
         r, s, p = _drop_args(ctx.drop)
-        call("tvae_embed_bwd", _p(ids), _p(_c(dout)), _p(dlut), B, L, d, vocab, r, s, p, _stream())
+        dout = _c(dout)
+        with _side_block(dout) if direct else _side_block():      # direct: atomics into lut.grad, nobody waits for them
+            call("tvae_embed_bwd", _p(ids), _p(dout), _p(dlut), B, L, d, vocab, r, s, p, _stream())
         if direct:
             _sink[0].done(ctx.P)
             return None, None, None, None

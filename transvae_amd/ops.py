@@ -720,7 +720,7 @@ class EmbedFn(torch.autograd.Function):
         dlut = _sink[0].target(ctx.P) if direct else torch.zeros((vocab, d), device=dout.device, dtype=torch.float32)
         r, s, p = _drop_args(ctx.drop)
         dout = _c(dout)
-        with _side_block(dout) if direct else _side_block():      # direct: atomics into lut.grad, nobody waits for them
+        with _side_block(dout, ids) if direct else _side_block():      # direct: atomics into lut.grad, nobody waits for them (ids: a temporary of the forward pass, read there too)
             call("tvae_embed_bwd", _p(ids), _p(dout), _p(dlut), B, L, d, vocab, r, s, p, _stream())
         if direct:
             _sink[0].done(ctx.P)

@@ -141,7 +141,16 @@ def _p(t):
     return C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """the current stream's handle for a launch.  torch.cuda.current_stream() builds a Stream object and resolves the device
+    through three Python layers (9 us per call, ~200 calls per train step: 2 ms of a trans1x-128 step that is bound by the
+    host's launch rate); the raw getter is the same lookup without them"""
+    if _raw_stream is not None and _cur_device is not None:
+        return C.c_void_p(_raw_stream(_cur_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Every GEMM launch of one fp32 train step of trans4x-256 (batch 500) with its shape: M, N, K and flags logged by a wrapper
 around ops.gemm, each launch timed with events (synchronised: durations are those of isolated warm launches), aggregated
-by shape with the achieved TFLOP/s.  python tools/gemm_shapes_step.py [dtype]"""
+by shape with the achieved TFLOP/s.  python tools/gemm_shapes_step.py [dtype [model]]"""
 import sys, os, collections
 os.environ["TVAE_WGRAD_STREAM"] = "0"      # isolated launches: the weight gradients stay on the compute stream, where the events are
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +11,7 @@ from transvae_amd import ops, synth
 
 if len(sys.argv) > 1:
     ops.set_compute_dtype(sys.argv[1])
-vae = bench.build_vae()
+vae = bench.build_vae(*sys.argv[2:3])
 vae.model.train()
 toks = synth.synth_tokens(500, seed=100).float()
 data = torch.cat([toks, torch.zeros(500, 1)], 1).cuda()
